@@ -1,0 +1,135 @@
+/*
+ * osqp_amd_engine.h -- thin C-ABI shim between the C host code and the HIP
+ * (gfx950) device engine.  Plain pointers and sizes only; no C++ or torch
+ * types.  Each entry point names the reference function(s) it replaces
+ * (paths relative to /root/reference).
+ *
+ * One `hipeng` = one QP resident on one GPU, with its own HIP stream; no
+ * process-global state (unlike lin_sys/direct/pardiso/pardiso_loader.c:29-32).
+ * All functions return 0 on success or a negative HIPENG_* code; they never
+ * fall back to the CPU.
+ */
+#ifndef OSQP_AMD_ENGINE_H
+#define OSQP_AMD_ENGINE_H
+
+#include "osqp_amd_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPENG_OK            0
+#define HIPENG_ERR_NO_DEVICE (-101)  /* no HIP device / runtime failure at create */
+#define HIPENG_ERR_HIP       (-102)  /* a HIP call failed (message on stderr)      */
+#define HIPENG_ERR_ARG       (-103)
+#define HIPENG_ERR_ALLOC     (-104)
+
+typedef struct hipeng hipeng;
+
+/* Mutable scalar parameters read by the kernels at launch. */
+typedef struct {
+  c_float sigma;        /* settings->sigma                                  */
+  c_float alpha;        /* settings->alpha                                  */
+  c_float pcg_eps_rel;  /* PCG stops at ||r||_2 <= max(eps_rel*||b||_2, eps_abs) */
+  c_float pcg_eps_abs;
+  c_int   pcg_max_iter; /* hard cap per linear solve                        */
+} hipeng_params;
+
+/* Scalars produced by one residual evaluation (replaces the reductions inside
+ * update_info / compute_pri_res / compute_dua_res / compute_pri_tol /
+ * compute_dua_tol / compute_rho_estimate, src/auxil.c:13-52, 227-359, and the
+ * cheap parts of is_primal_infeasible / is_dual_infeasible, :361-512). */
+typedef struct {
+  c_float pri_res_u, pri_res_s;     /* ||Einv(Ax-z)||, ||Ax-z||              */
+  c_float z_u, z_s, Ax_u, Ax_s;     /* ||Einv z||, ||z||, ||Einv Ax||, ||Ax|| */
+  c_float dua_res_u, dua_res_s;     /* ||Dinv(q+Px+A'y)|| (no cinv), scaled  */
+  c_float q_u, q_s, Aty_u, Aty_s, Px_u, Px_s;
+  c_float obj_scaled;               /* 1/2 x'Px + q'x in scaled space         */
+  c_float dy_norm_u, dy_norm_s;     /* ||E dy_proj||, ||dy_proj||             */
+  c_float dy_lhs;                   /* u'max(dy,0) + l'min(dy,0)              */
+  c_float dx_norm_u, dx_norm_s;     /* ||D dx||, ||dx||                       */
+  c_float q_dx;                     /* q'dx                                   */
+  /* filled by hipeng_certificates only */
+  c_float Atdy_u, Atdy_s;           /* ||Dinv A'dy_proj||, ||A'dy_proj||       */
+  c_float Pdx_u, Pdx_s;             /* ||Dinv P dx||, ||P dx||                 */
+  c_float Adx_viol;                 /* number of rows violating the A dx test */
+} hipeng_scalars;
+
+typedef struct {
+  c_int admm_done;       /* iterations completed by the last hipeng_run_admm  */
+  c_int pcg_iters_total; /* PCG iterations since create/reset                 */
+  c_int pcg_iters_last;  /* PCG iterations of the most recent linear solve    */
+  c_int pcg_iters_max;   /* max per solve since the last hipeng_run_admm call */
+  c_int pcg_forced;      /* solves accepted at pcg_max_iter without converging */
+  c_int graph_launches;
+  c_int kernels_per_pcg_iter;
+} hipeng_stats;
+
+/* Create the device-resident problem.  P (upper triangle) and A are the
+ * workspace's scaled matrices in CSC with int64 indices; they are re-indexed
+ * to int32 and uploaded as CSR(A) and the fused row matrix [P | A'].
+ * Replaces the allocation + init part of init_linsys_solver
+ * (src/lin_sys.c:56-75, lin_sys/direct/qdldl/qdldl_interface.c:177-323). */
+int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_float *q,
+                  const c_float *l, const c_float *u, const c_float *rho_vec,
+                  const hipeng_params *prm, int device);
+void hipeng_destroy(hipeng *e);
+
+int hipeng_set_params(hipeng *e, const hipeng_params *prm);
+/* D, E, Dinv, Einv vectors (NULL = identity) and cost scaling c: needed only
+ * for the unscaled norms of hipeng_residuals (src/scaling.c:177-192). */
+int hipeng_set_scaling(hipeng *e, const c_float *D, const c_float *E, c_float c);
+int hipeng_upload_q(hipeng *e, const c_float *q);                      /* osqp_update_lin_cost, osqp.c:765 */
+int hipeng_upload_bounds(hipeng *e, const c_float *l, const c_float *u); /* osqp_update_bounds, osqp.c:797 */
+/* update_rho_vec of the vtable (qdldl_interface.c:396-410): re-uploads rho and
+ * rebuilds the Jacobi preconditioner diag(P)+sigma+sum_i rho_i A_ij^2. */
+int hipeng_upload_rho(hipeng *e, const c_float *rho_vec);
+/* update_matrices of the vtable (qdldl_interface.c:381-393): new values, same
+ * sparsity. */
+int hipeng_upload_matrices(hipeng *e, const csc *P, const csc *A);
+/* cold_start (auxil.c:155) / osqp_warm_start* (osqp.c:942-1007): x, y NULL =
+ * keep; z is recomputed as A x on the device when x is given. */
+int hipeng_cold_start(hipeng *e);
+int hipeng_set_iterates(hipeng *e, const c_float *x, const c_float *y);
+/* overwrite z (and the PCG's z~ warm-start image) -- used when polish adopts
+ * its (x, z, y) (src/polish.c:321-325) */
+int hipeng_set_z(hipeng *e, const c_float *z);
+
+/* Run `count` ADMM iterations (osqp.c:356-370: swap, update_xz_tilde,
+ * update_x, update_z, update_y) entirely on the device. */
+int hipeng_run_admm(hipeng *e, c_int count);
+/* Evaluate all residual scalars for the current iterates (device reductions,
+ * one small D2H copy). */
+int hipeng_residuals(hipeng *e, hipeng_scalars *out);
+/* Second stage of the infeasibility tests: A'dy, P dx, A dx (auxil.c:401-417,
+ * 456-497).  eps_dx = eps_dual_inf * ||dx|| threshold for the A dx row test;
+ * unscaled != 0 applies Einv to A dx first. */
+int hipeng_certificates(hipeng *e, c_float eps_dx, int unscaled, hipeng_scalars *inout);
+/* Copy device vectors to host arrays (NULL = skip).  dy is the projected
+ * delta_y when `dy_projected` is nonzero. */
+int hipeng_download(hipeng *e, c_float *x, c_float *y, c_float *z, c_float *dx,
+                    c_float *dy, int dy_projected);
+int hipeng_get_stats(hipeng *e, hipeng_stats *st);
+int hipeng_sync(hipeng *e);
+
+/* Plugin-boundary solve (LinSysSolver.solve, include/types.h:300-301;
+ * qdldl_interface.c:350-376): b = [sigma x - q ; z - y/rho] on the host is
+ * overwritten by [x_tilde ; z_tilde]. */
+int hipeng_kkt_solve(hipeng *e, c_float *b);
+
+/* Kernel-level entry points used by the parity tests (host in, host out):
+ * which = 0: y = A x   (mat_vec, lin_alg.c:241-271)
+ *         1: y = A' x  (mat_tpose_vec, lin_alg.c:273-322)
+ *         2: y = P x   (mat_vec + mat_tpose_vec skip_diag on triu P) */
+int hipeng_spmv(hipeng *e, int which, const c_float *x, c_float *y);
+/* Time `reps` back-to-back launches of one hot kernel on the engine stream with
+ * HIP events; returns average microseconds per launch in *usec.
+ * which = 0: K1 (A p), 1: K2 ([P|A'] apply), 2: K3 (vector update + dots). */
+int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec);
+/* Algorithmic bytes of one launch of the kernels above. */
+int hipeng_kernel_bytes(hipeng *e, int which, double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

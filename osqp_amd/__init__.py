@@ -1,0 +1,65 @@
+"""osqp_amd -- MI355X-native drop-in for the OSQP ADMM hot path.
+
+Python here is plumbing only (ctypes over the C ABI of libosqp_amd.so).  The
+interface mirrors the reference's Python wrapper: `OSQP().setup(P, q, A, l, u,
+**settings)`, `.solve()`, `.update(...)`, `.warm_start(...)`.
+"""
+import ctypes as C
+
+from . import _abi as abi
+from ._lib import lib, build, LIB_PATH
+from .interface import SolverHandle, Results
+
+__all__ = ["OSQP", "abi", "lib", "build", "engine_options", "set_engine_options"]
+
+
+class _Options(C.Structure):
+    _fields_ = [("pcg_eps_rel", abi.c_float), ("pcg_eps_abs", abi.c_float),
+                ("pcg_max_iter", abi.c_int), ("device", abi.c_int)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("pcg_iters_total", abi.c_int), ("pcg_iters_last", abi.c_int),
+                ("pcg_forced", abi.c_int), ("graph_launches", abi.c_int),
+                ("host_syncs", abi.c_int)]
+
+
+def engine_options():
+    o = _Options()
+    f = lib().osqp_amd_get_options
+    f.restype = None
+    f.argtypes = [C.POINTER(_Options)]
+    f(C.byref(o))
+    return {k: getattr(o, k) for k, _ in _Options._fields_}
+
+
+def set_engine_options(**kw):
+    cur = engine_options()
+    cur.update(kw)
+    o = _Options(**cur)
+    f = lib().osqp_amd_set_options
+    f.restype = None
+    f.argtypes = [C.POINTER(_Options)]
+    f(C.byref(o))
+
+
+class OSQP(SolverHandle):
+    """One QP resident on one MI355X (HIP PCG engine behind the reference API)."""
+
+    def __init__(self):
+        super().__init__(lib(), "")
+
+    def stats(self):
+        s = _Stats()
+        f = self._lib.osqp_amd_get_stats
+        f.restype = abi.c_int
+        f.argtypes = [C.POINTER(abi.OSQPWorkspace), C.POINTER(_Stats)]
+        if f(self._work, C.byref(s)):
+            raise RuntimeError("no engine")
+        return {k: getattr(s, k) for k, _ in _Stats._fields_}
+
+    def engine(self):
+        f = self._lib.osqp_amd_engine
+        f.restype = C.c_void_p
+        f.argtypes = [C.POINTER(abi.OSQPWorkspace)]
+        return f(self._work)

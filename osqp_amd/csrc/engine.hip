@@ -1,0 +1,1293 @@
+// engine.hip -- device-resident OSQP ADMM engine for gfx950 (MI355X, CDNA4).
+//
+// What runs here (all fp64, int32 indices, one HIP stream per engine):
+//   * the ADMM iteration of osqp_solve (reference src/osqp.c:356-370,
+//     src/auxil.c:161-225, src/proj.c:4-14) as hipGraph replays of
+//       k_pcg_init -> K x { k_pcg_Ap, k_pcg_Kp, k_pcg_update } -> k_admm_finalize
+//   * the linear solve of update_xz_tilde as an indirect method: Jacobi-PCG on
+//       (P + sigma I + A' diag(rho) A) x~ = sigma x - q + A'(rho.z - y)
+//     (docs/solver/index.rst:50-55 in the reference), then z~ = A x~
+//   * residual / tolerance / rho-estimate / infeasibility reductions of
+//     update_info + check_termination (src/auxil.c:13-52, 227-512)
+//
+// Data layout in HBM:
+//   A      : CSR (row gather for A x), built from the CSC the API hands over
+//   M      : fused row matrix [P_full | A'] (n rows, n+m columns).  Row j holds
+//            P(j, j..n) ascending, then P(j, 0..j) ascending, then column j of
+//            A with column ids n+i -- i.e. exactly the summation order of the
+//            reference's mat_vec + mat_tpose_vec(skip_diag) + mat_tpose_vec
+//            (lin_alg.c:241-322), so P x and A' y are reproduced bit for bit.
+//   vectors: [x | y], [x~ | rho z~], [0 | rho z - y], [p | t] (x2) are stored
+//            contiguously so one fused SpMV over M consumes "n-part | m-part".
+//
+// SpMV scheme (all matrices): row blocks of <= chunk non-zeros are streamed
+// with fully coalesced index/value loads, the products val*x[col] are staged in
+// LDS, then each row segment is summed sequentially from LDS by one lane
+// (CSR-stream).  Rows longer than a chunk are reduced by the whole workgroup
+// with 64-lane wavefront shuffles.  Dot products are written as one partial
+// per workgroup and re-reduced in a fixed order by every workgroup of the next
+// kernel, so results are bitwise reproducible and PCG scalars never visit the
+// host.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <new>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <map>
+#include <algorithm>
+#include "../../include/osqp_amd_engine.h"
+
+#define TB 256            // threads per workgroup (4 wavefronts of 64)
+#define MAX_CHUNK 2048    // products staged in LDS per workgroup (x2 for dual stream)
+#define MAX_PARTS 1024    // upper bound on workgroups that emit dot partials
+#define INF_BOUND 1e26    // OSQP_INFTY * MIN_SCALING
+
+#define HIPCHK(call)                                                            \
+  do {                                                                          \
+    hipError_t _e = (call);                                                     \
+    if (_e != hipSuccess) {                                                     \
+      fprintf(stderr, "osqp_amd: HIP error %s at %s:%d (%s)\n",                 \
+              hipGetErrorString(_e), __FILE__, __LINE__, #call);                \
+      return HIPENG_ERR_HIP;                                                    \
+    }                                                                           \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// device-side descriptors
+// ---------------------------------------------------------------------------
+struct RowBlk { int r0, r1, k0, k1; };
+
+struct DevMat {
+  int nrows, nblk;
+  const int    *rowptr;
+  const int    *col;
+  const double *val;
+  const int    *split;   // M only: first entry of the A' part of each row
+  const RowBlk *blk;
+};
+
+// Written by kernels only; read by the host between windows.
+struct State {
+  int    run;          // this ADMM iteration is active (written by the first kernel)
+  int    done;         // PCG converged (written by k_pcg_Ap)
+  int    stalled;      // PCG ran out of unrolled iterations (written by finalize)
+  int    neg_curv;     // p'Kp <= 0 seen
+  int    iters[2];     // PCG iterations of the current solve (ping-pong on parity)
+  int    neg_curv_seen;
+  int    iters_last;
+  int    iters_max;
+  int    forced;
+  long long iters_total;
+  long long admm_done;
+  double rz[2];
+  double tol2;
+};
+
+struct Params {          // mutable scalars (host writes, kernels read)
+  double sigma, alpha, eps_rel, eps_abs, cinv;
+  int    pcg_max_iter, use_cvec, has_scaling, pad;
+};
+
+struct Ctx {             // static pointers / sizes, passed by value
+  int n, m;
+  DevMat A, M;
+  int gridA, gridM;      // launch grids (>=1) of row kernels over A / over M
+  double *xy, *z, *zt, *va, *vb, *q, *l, *u, *rho, *rhoinv, *minv, *pdiag;
+  double *r, *zz, *kp, *pt0, *pt1, *dxy, *dy, *cvec;
+  double *D, *Dinv, *E, *Einv;
+  double *part_rz, *part_rr, *part_bb, *part_pkp, *part_s0, *part_s1, *part_s2;
+  double *scal;          // reduction outputs (see SC_* below)
+  State  *st;
+  const Params *prm;
+};
+
+enum {  // slots of Ctx::scal (max slots are bit patterns of non-negative doubles)
+  SC_PRI_U, SC_PRI_S, SC_Z_U, SC_Z_S, SC_AX_U, SC_AX_S,
+  SC_DUA_U, SC_DUA_S, SC_Q_U, SC_Q_S, SC_ATY_U, SC_ATY_S, SC_PX_U, SC_PX_S,
+  SC_DYN_U, SC_DYN_S, SC_DXN_U, SC_DXN_S,
+  SC_ATDY_U, SC_ATDY_S, SC_PDX_U, SC_PDX_S, SC_ADX_VIOL,
+  SC_OBJ, SC_DYLHS, SC_QDX,
+  SC_COUNT
+};
+
+// ---------------------------------------------------------------------------
+// wavefront / workgroup reductions (wave = 64 lanes on gfx950)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum over the workgroup, result broadcast to every thread.  `red` holds >= 5
+// doubles of LDS.  Fixed tree => deterministic.
+__device__ __forceinline__ double block_sum(double v, double *red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) red[4] = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  return red[4];
+}
+
+// Re-reduce up to three arrays of per-workgroup partials (same length).
+template <int NA>
+__device__ __forceinline__ void reduce_parts(const double *a0, const double *a1,
+                                             const double *a2, int count,
+                                             double *red, double out[NA]) {
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int i = threadIdx.x; i < count; i += TB) {
+    s0 += a0[i];
+    if (NA > 1) s1 += a1[i];
+    if (NA > 2) s2 += a2[i];
+  }
+  out[0] = block_sum(s0, red);
+  if (NA > 1) out[1] = block_sum(s1, red);
+  if (NA > 2) out[2] = block_sum(s2, red);
+}
+
+__device__ __forceinline__ void atomic_max_pos(double *slot, double v) {
+  // v >= 0: IEEE ordering of non-negative doubles equals unsigned ordering
+  atomicMax(reinterpret_cast<unsigned long long *>(slot),
+            static_cast<unsigned long long>(__double_as_longlong(v)));
+}
+
+__device__ __forceinline__ void block_max_to(double v, double *slot, double *red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomic_max_pos(slot, fmax(fmax(red[0], red[1]), fmax(red[2], red[3])));
+}
+
+// ---------------------------------------------------------------------------
+// CSR-stream building blocks
+// ---------------------------------------------------------------------------
+// Stage products of the block's entries with one or two input vectors.
+// GATHER_P: input 0 is formed on the fly as zz[c] + beta*pold[c] for c < n
+// (the PCG direction update fused into the gather).
+template <int NV>
+__device__ __forceinline__ void stage_products(const DevMat &Mx, const RowBlk b,
+                                               const double *in0, const double *in1,
+                                               double *l0, double *l1) {
+  const int cnt = b.k1 - b.k0;
+  for (int k = threadIdx.x; k < cnt; k += TB) {
+    const int c = Mx.col[b.k0 + k];
+    const double v = Mx.val[b.k0 + k];
+    l0[k] = v * in0[c];
+    if (NV == 2) l1[k] = v * in1[c];
+  }
+}
+
+// Sequential (reference-order) sum of one row segment held in LDS.
+__device__ __forceinline__ double row_sum(const double *l, int a, int b) {
+  double s = 0.0;
+  for (int k = a; k < b; ++k) s += l[k];
+  return s;
+}
+
+// A row that does not fit one chunk: whole-workgroup strided reduction of
+// sum_k val[k]*in[col[k]] over [ka, kb).  (Summation order differs from the
+// sequential reference order; only rows longer than MAX_CHUNK take this path.)
+__device__ __forceinline__ double long_row_dot(const DevMat &Mx, int ka, int kb,
+                                               const double *in, double *red) {
+  double s = 0.0;
+  for (int k = ka + threadIdx.x; k < kb; k += TB) s += Mx.val[k] * in[Mx.col[k]];
+  return block_sum(s, red);
+}
+
+#define LDS_DECL(NV)                                   \
+  __shared__ double lprod[(NV) * MAX_CHUNK];           \
+  __shared__ double red[8]
+
+// ---------------------------------------------------------------------------
+// PCG kernels
+// ---------------------------------------------------------------------------
+// Every row kernel walks its row blocks with a workgroup-stride loop, so the
+// number of dot-product partials equals the launch grid (<= MAX_PARTS).
+
+// First kernel of an ADMM iteration: right-hand side b = sigma x - q + A'(rho z - y)
+// (compute_rhs folded into the reduced system), initial residual r = b - K x~0
+// with the warm start x~0 = previous x~, preconditioned residual and the three
+// start-up dot products.  One dual-stream pass over M.
+__global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
+  State *st = c.st;
+  if (st->stalled) { if (blockIdx.x == 0 && threadIdx.x == 0) st->run = 0; return; }
+  LDS_DECL(2);
+  const Params prm = *c.prm;
+  double prz = 0, prr = 0, pbb = 0;
+  for (int bi = blockIdx.x; bi < c.M.nblk; bi += gridDim.x) {
+    const RowBlk b = c.M.blk[bi];
+    const bool longrow = (b.k1 - b.k0) > MAX_CHUNK;
+    if (!longrow) {
+      stage_products<2>(c.M, b, c.va, c.vb, lprod, lprod + MAX_CHUNK);
+      __syncthreads();
+    }
+    for (int j = b.r0 + (longrow ? 0 : threadIdx.x); j < b.r1; j += (longrow ? 1 : TB)) {
+      double sA, sB;
+      if (longrow) {
+        sA = long_row_dot(c.M, b.k0, b.k1, c.va, red);
+        sB = long_row_dot(c.M, b.k0, b.k1, c.vb, red);
+      } else {
+        const int a0 = c.M.rowptr[j] - b.k0, a1 = c.M.rowptr[j + 1] - b.k0;
+        sA = row_sum(lprod, a0, a1);
+        sB = row_sum(lprod + MAX_CHUNK, a0, a1);
+      }
+      if (!longrow || threadIdx.x == 0) {
+        const double base = prm.use_cvec ? c.cvec[j] : (prm.sigma * c.xy[j] - c.q[j]);
+        const double bj = base + sB;
+        const double rj = bj - prm.sigma * c.va[j] - sA;
+        const double zj = c.minv[j] * rj;
+        c.r[j] = rj;
+        c.zz[j] = zj;
+        prz += rj * zj; prr += rj * rj; pbb += bj * bj;
+      }
+    }
+    __syncthreads();
+  }
+  prz = block_sum(prz, red); prr = block_sum(prr, red); pbb = block_sum(pbb, red);
+  if (threadIdx.x == 0) {
+    c.part_rz[blockIdx.x] = prz; c.part_rr[blockIdx.x] = prr; c.part_bb[blockIdx.x] = pbb;
+    if (blockIdx.x == 0) {
+      st->run = 1; st->done = 0; st->neg_curv = 0; st->iters[0] = 0; st->iters[1] = 0;
+    }
+  }
+}
+
+// PCG step 1: convergence test, beta, direction p = zz + beta p_old (fused into
+// the gather and written once per element), t = rho . (A p).
+// flags: bit0 = first iteration of a solve, bit1 = first kernel of a
+// "continue" graph (runs only while stalled), bit2 = benchmark (no early exit,
+// fixed beta).
+// Scalars that a kernel both reads and updates are ping-ponged on the parity of
+// `it` (rz[], iters[]) so that a late workgroup never observes a value written
+// by workgroup 0 of the same launch.
+__global__ void __launch_bounds__(TB) k_pcg_Ap(Ctx c, int it, int flags) {
+  State *st = c.st;
+  const bool first = flags & 1, cont = flags & 2, bench = flags & 4;
+  if (cont) {
+    const int act = st->stalled;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->run = act;
+    if (!act) return;
+  } else if (!bench && (!st->run || st->done)) return;
+  LDS_DECL(1);
+  const Params prm = *c.prm;
+  double sums[3];
+  reduce_parts<3>(c.part_rr, c.part_rz, c.part_bb, c.gridM, red, sums);
+  const double rr = sums[0], rz_new = sums[1];
+  const int iters_prev = st->iters[(it + 1) & 1];
+  double tol2, beta;
+  if (first) {
+    tol2 = fmax(prm.eps_rel * prm.eps_rel * sums[2], prm.eps_abs * prm.eps_abs);
+    beta = 0.0;
+  } else {
+    tol2 = st->tol2;
+    beta = rz_new / st->rz[(it + 1) & 1];
+  }
+  if (bench) beta = 0.5;
+  const bool conv = rr <= tol2;
+  const bool giveup = iters_prev >= prm.pcg_max_iter || st->neg_curv;
+  if (!bench && (conv || giveup)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      st->done = conv ? 1 : 2;
+      if (first) { st->tol2 = tol2; st->rz[it & 1] = rz_new; }
+    }
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->rz[it & 1] = rz_new;
+    if (first) st->tol2 = tol2;
+    st->iters[it & 1] = iters_prev + 1;
+  }
+  const double *pold = (it & 1) ? c.pt0 : c.pt1;
+  double *pnew = (it & 1) ? c.pt1 : c.pt0;
+  // own slice of the new direction
+  for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB)
+    pnew[j] = first ? c.zz[j] : (c.zz[j] + beta * pold[j]);
+  for (int bi = blockIdx.x; bi < c.A.nblk; bi += gridDim.x) {
+    const RowBlk b = c.A.blk[bi];
+    const int cnt = b.k1 - b.k0;
+    if (cnt > MAX_CHUNK) {   // single long row
+      double s = 0.0;
+      for (int k = b.k0 + threadIdx.x; k < b.k1; k += TB) {
+        const int cc = c.A.col[k];
+        const double pv = first ? c.zz[cc] : (c.zz[cc] + beta * pold[cc]);
+        s += c.A.val[k] * pv;
+      }
+      s = block_sum(s, red);
+      if (threadIdx.x == 0) pnew[c.n + b.r0] = c.rho[b.r0] * s;
+    } else {
+      for (int k = threadIdx.x; k < cnt; k += TB) {
+        const int cc = c.A.col[b.k0 + k];
+        const double pv = first ? c.zz[cc] : (c.zz[cc] + beta * pold[cc]);
+        lprod[k] = c.A.val[b.k0 + k] * pv;
+      }
+      __syncthreads();
+      for (int i = b.r0 + threadIdx.x; i < b.r1; i += TB) {
+        const double s = row_sum(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0);
+        pnew[c.n + i] = c.rho[i] * s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// PCG step 2: Kp = P p + sigma p + A' t, and the partials of p'Kp.
+__global__ void __launch_bounds__(TB) k_pcg_Kp(Ctx c, int it, int flags) {
+  State *st = c.st;
+  if (!(flags & 4) && (!st->run || st->done)) return;
+  LDS_DECL(1);
+  const double sigma = c.prm->sigma;
+  const double *pt = (it & 1) ? c.pt1 : c.pt0;
+  double ppkp = 0.0;
+  for (int bi = blockIdx.x; bi < c.M.nblk; bi += gridDim.x) {
+    const RowBlk b = c.M.blk[bi];
+    if ((b.k1 - b.k0) > MAX_CHUNK) {
+      const double s = long_row_dot(c.M, b.k0, b.k1, pt, red);
+      if (threadIdx.x == 0) {
+        const double pj = pt[b.r0], kpj = s + sigma * pj;
+        c.kp[b.r0] = kpj; ppkp += pj * kpj;
+      }
+    } else {
+      stage_products<1>(c.M, b, pt, nullptr, lprod, nullptr);
+      __syncthreads();
+      for (int j = b.r0 + threadIdx.x; j < b.r1; j += TB) {
+        const double s = row_sum(lprod, c.M.rowptr[j] - b.k0, c.M.rowptr[j + 1] - b.k0);
+        const double pj = pt[j], kpj = s + sigma * pj;
+        c.kp[j] = kpj;
+        ppkp += pj * kpj;
+      }
+    }
+    __syncthreads();
+  }
+  ppkp = block_sum(ppkp, red);
+  if (threadIdx.x == 0) c.part_pkp[blockIdx.x] = ppkp;
+}
+
+// PCG step 3: alpha, x~ += alpha p, r -= alpha Kp, zz = Minv r, partials of r'zz, r'r.
+__global__ void __launch_bounds__(TB) k_pcg_update(Ctx c, int it, int flags) {
+  State *st = c.st;
+  const bool bench = flags & 4;
+  if (!bench && (!st->run || st->done)) return;
+  __shared__ double red[8];
+  double pkp[1];
+  reduce_parts<1>(c.part_pkp, nullptr, nullptr, c.gridM, red, pkp);
+  double alpha = 0.0;
+  if (bench) alpha = 1e-3;
+  else if (pkp[0] > 0.0) alpha = st->rz[it & 1] / pkp[0];
+  else if (blockIdx.x == 0 && threadIdx.x == 0) st->neg_curv = 1;
+  const double *pt = (it & 1) ? c.pt1 : c.pt0;
+  double prz = 0, prr = 0;
+  for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
+    c.va[j] += alpha * pt[j];
+    const double rj = c.r[j] - alpha * c.kp[j];
+    const double zj = c.minv[j] * rj;
+    c.r[j] = rj; c.zz[j] = zj;
+    prz += rj * zj; prr += rj * rj;
+  }
+  prz = block_sum(prz, red); prr = block_sum(prr, red);
+  if (threadIdx.x == 0) { c.part_rz[blockIdx.x] = prz; c.part_rr[blockIdx.x] = prr; }
+}
+
+// Last kernel of an ADMM iteration: z~ = A x~, then update_x / update_z (+project)
+// / update_y (auxil.c:185-225, proj.c:4-14) and the m-parts of the next
+// right-hand side.  If the PCG has not converged within the unrolled
+// iterations the iteration is left untouched and `stalled` is raised.
+__global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
+  State *st = c.st;
+  if (!st->run) return;
+  LDS_DECL(1);
+  const Params prm = *c.prm;
+  double rr[1];
+  reduce_parts<1>(c.part_rr, nullptr, nullptr, c.gridM, red, rr);
+  const int iters = st->iters[0] > st->iters[1] ? st->iters[0] : st->iters[1];
+  const bool conv = st->done == 1 || rr[0] <= st->tol2;
+  const bool force = st->done == 2 || iters >= prm.pcg_max_iter || st->neg_curv;
+  if (!conv && !force) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->stalled = 1;
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->stalled = 0;
+    st->admm_done += 1;
+    st->iters_last = iters;
+    st->iters_total += iters;
+    if (iters > st->iters_max) st->iters_max = iters;
+    if (!conv) st->forced += 1;
+    if (st->neg_curv) st->neg_curv_seen += 1;
+  }
+  const double alpha = prm.alpha, oma = 1.0 - prm.alpha;
+  double *x = c.xy, *y = c.xy + c.n;
+  for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
+    const double xo = x[j];
+    const double xn = alpha * c.va[j] + oma * xo;
+    c.dxy[j] = xn - xo;
+    x[j] = xn;
+  }
+  for (int bi = blockIdx.x; bi < c.A.nblk; bi += gridDim.x) {
+    const RowBlk b = c.A.blk[bi];
+    const bool longrow = (b.k1 - b.k0) > MAX_CHUNK;
+    if (!longrow) {
+      stage_products<1>(c.A, b, c.va, nullptr, lprod, nullptr);
+      __syncthreads();
+    }
+    for (int i = b.r0 + (longrow ? 0 : threadIdx.x); i < b.r1; i += (longrow ? 1 : TB)) {
+      double zt;
+      if (longrow) zt = long_row_dot(c.A, b.k0, b.k1, c.va, red);
+      else zt = row_sum(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0);
+      if (!longrow || threadIdx.x == 0) {
+        const double rho = c.rho[i], rinv = c.rhoinv[i], yo = y[i], zo = c.z[i];
+        double v = alpha * zt + oma * zo + rinv * yo;
+        v = fmax(v, c.l[i]);
+        const double zn = fmin(v, c.u[i]);
+        const double dy = rho * (alpha * zt + oma * zo - zn);
+        const double yn = yo + dy;
+        c.z[i] = zn; y[i] = yn; c.dy[i] = dy; c.zt[i] = zt;
+        c.va[c.n + i] = rho * zt;
+        c.vb[c.n + i] = rho * zn - yn;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// auxiliary kernels
+// ---------------------------------------------------------------------------
+// Jacobi preconditioner: Minv_j = 1 / (P_jj + sigma + sum_i rho_i A_ij^2)
+__global__ void __launch_bounds__(TB) k_precond(Ctx c) {
+  const double sigma = c.prm->sigma;
+  for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
+    double s = c.pdiag[j] + sigma;
+    for (int k = c.M.split[j]; k < c.M.rowptr[j + 1]; ++k) {
+      const double a = c.M.val[k];
+      s += c.rho[c.M.col[k] - c.n] * a * a;
+    }
+    c.minv[j] = 1.0 / s;
+  }
+}
+
+// m-parts of the PCG input vectors from (z, z~, y, rho); rhoinv from rho.
+__global__ void __launch_bounds__(TB) k_refresh_m(Ctx c) {
+  const double *y = c.xy + c.n;
+  for (int i = blockIdx.x * TB + threadIdx.x; i < c.m; i += gridDim.x * TB) {
+    const double rho = c.rho[i];
+    c.rhoinv[i] = 1.0 / rho;
+    c.va[c.n + i] = rho * c.zt[i];
+    c.vb[c.n + i] = rho * c.z[i] - y[i];
+  }
+}
+
+// Generic SpMV used by set_iterates (z = A x) and by the kernel-level tests.
+// sel: 0 = whole row, 1 = entries before split (P part), 2 = from split (A' part)
+__global__ void __launch_bounds__(TB) k_spmv(DevMat Mx, const double *in, double *out, int sel) {
+  LDS_DECL(1);
+  for (int bi = blockIdx.x; bi < Mx.nblk; bi += gridDim.x) {
+    const RowBlk b = Mx.blk[bi];
+    if ((b.k1 - b.k0) > MAX_CHUNK) {
+      int ka = b.k0, kb = b.k1;
+      if (sel == 1) kb = Mx.split[b.r0];
+      if (sel == 2) ka = Mx.split[b.r0];
+      const double s = long_row_dot(Mx, ka, kb, in, red);
+      if (threadIdx.x == 0) out[b.r0] = s;
+    } else {
+      stage_products<1>(Mx, b, in, nullptr, lprod, nullptr);
+      __syncthreads();
+      for (int r = b.r0 + threadIdx.x; r < b.r1; r += TB) {
+        int a0 = Mx.rowptr[r] - b.k0, a1 = Mx.rowptr[r + 1] - b.k0;
+        if (sel == 1) a1 = Mx.split[r] - b.k0;
+        if (sel == 2) a0 = Mx.split[r] - b.k0;
+        out[r] = row_sum(lprod, a0, a1);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Residuals, tolerances' norms, rho-estimate norms, objective and the cheap
+// halves of both infeasibility tests in ONE launch:
+//   workgroups [0, gridA)          : rows of A (A x, primal side, delta_y)
+//   workgroups [gridA, gridA+gridM): rows of M (P x, A'y, dual side, delta_x)
+__global__ void __launch_bounds__(TB) k_residuals(Ctx c) {
+  LDS_DECL(1);
+  const Params prm = *c.prm;
+  const bool sc = prm.has_scaling;
+  double *x = c.xy;
+  if ((int)blockIdx.x < c.gridA) {
+    double m_pu = 0, m_ps = 0, m_zu = 0, m_zs = 0, m_au = 0, m_as = 0, m_du = 0, m_ds = 0, lhs = 0;
+    for (int bi = blockIdx.x; bi < c.A.nblk; bi += c.gridA) {
+      const RowBlk b = c.A.blk[bi];
+      const bool longrow = (b.k1 - b.k0) > MAX_CHUNK;
+      if (!longrow) { stage_products<1>(c.A, b, x, nullptr, lprod, nullptr); __syncthreads(); }
+      for (int i = b.r0 + (longrow ? 0 : threadIdx.x); i < b.r1; i += (longrow ? 1 : TB)) {
+        double ax;
+        if (longrow) ax = long_row_dot(c.A, b.k0, b.k1, x, red);
+        else ax = row_sum(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0);
+        if (!longrow || threadIdx.x == 0) {
+          const double zi = c.z[i], pr = ax + (-1.0) * zi;
+          const double ei = sc ? c.Einv[i] : 1.0, e = sc ? c.E[i] : 1.0;
+          m_pu = fmax(m_pu, fabs(ei * pr)); m_ps = fmax(m_ps, fabs(pr));
+          m_zu = fmax(m_zu, fabs(ei * zi)); m_zs = fmax(m_zs, fabs(zi));
+          m_au = fmax(m_au, fabs(ei * ax)); m_as = fmax(m_as, fabs(ax));
+          // delta_y projected on the polar of the recession cone (auxil.c:375-388)
+          double dy = c.dy[i];
+          const double li = c.l[i], ui = c.u[i];
+          if (ui > INF_BOUND) { if (li < -INF_BOUND) dy = 0.0; else dy = fmin(dy, 0.0); }
+          else if (li < -INF_BOUND) dy = fmax(dy, 0.0);
+          c.dxy[c.n + i] = dy;
+          m_du = fmax(m_du, fabs(e * dy)); m_ds = fmax(m_ds, fabs(dy));
+          lhs += ui * fmax(dy, 0.0) + li * fmin(dy, 0.0);
+        }
+      }
+      __syncthreads();
+    }
+    block_max_to(m_pu, c.scal + SC_PRI_U, red); block_max_to(m_ps, c.scal + SC_PRI_S, red);
+    block_max_to(m_zu, c.scal + SC_Z_U, red);   block_max_to(m_zs, c.scal + SC_Z_S, red);
+    block_max_to(m_au, c.scal + SC_AX_U, red);  block_max_to(m_as, c.scal + SC_AX_S, red);
+    block_max_to(m_du, c.scal + SC_DYN_U, red); block_max_to(m_ds, c.scal + SC_DYN_S, red);
+    lhs = block_sum(lhs, red);
+    if (threadIdx.x == 0) c.part_s0[blockIdx.x] = lhs;
+    return;
+  }
+  const int bid = blockIdx.x - c.gridA;
+  double m_du = 0, m_ds = 0, m_qu = 0, m_qs = 0, m_tu = 0, m_ts = 0, m_pu = 0, m_ps = 0;
+  double m_xu = 0, m_xs = 0, obj = 0, qdx = 0;
+  for (int bi = bid; bi < c.M.nblk; bi += c.gridM) {
+    const RowBlk b = c.M.blk[bi];
+    const bool longrow = (b.k1 - b.k0) > MAX_CHUNK;
+    if (!longrow) { stage_products<1>(c.M, b, c.xy, nullptr, lprod, nullptr); __syncthreads(); }
+    for (int j = b.r0 + (longrow ? 0 : threadIdx.x); j < b.r1; j += (longrow ? 1 : TB)) {
+      double px, aty;
+      if (longrow) {
+        px  = long_row_dot(c.M, b.k0, c.M.split[j], c.xy, red);
+        aty = long_row_dot(c.M, c.M.split[j], b.k1, c.xy, red);
+      } else {
+        const int a0 = c.M.rowptr[j] - b.k0, as = c.M.split[j] - b.k0, a1 = c.M.rowptr[j + 1] - b.k0;
+        px = row_sum(lprod, a0, as);
+        aty = row_sum(lprod, as, a1);
+      }
+      if (!longrow || threadIdx.x == 0) {
+        const double qj = c.q[j], xj = x[j], dxj = c.dxy[j];
+        double dr = qj + px;
+        if (c.m > 0) dr = dr + aty;
+        const double di = sc ? c.Dinv[j] : 1.0, d = sc ? c.D[j] : 1.0;
+        m_du = fmax(m_du, fabs(di * dr));  m_ds = fmax(m_ds, fabs(dr));
+        m_qu = fmax(m_qu, fabs(di * qj));  m_qs = fmax(m_qs, fabs(qj));
+        m_tu = fmax(m_tu, fabs(di * aty)); m_ts = fmax(m_ts, fabs(aty));
+        m_pu = fmax(m_pu, fabs(di * px));  m_ps = fmax(m_ps, fabs(px));
+        m_xu = fmax(m_xu, fabs(d * dxj));  m_xs = fmax(m_xs, fabs(dxj));
+        obj += xj * (0.5 * px + qj);
+        qdx += qj * dxj;
+      }
+    }
+    __syncthreads();
+  }
+  block_max_to(m_du, c.scal + SC_DUA_U, red); block_max_to(m_ds, c.scal + SC_DUA_S, red);
+  block_max_to(m_qu, c.scal + SC_Q_U, red);   block_max_to(m_qs, c.scal + SC_Q_S, red);
+  block_max_to(m_tu, c.scal + SC_ATY_U, red); block_max_to(m_ts, c.scal + SC_ATY_S, red);
+  block_max_to(m_pu, c.scal + SC_PX_U, red);  block_max_to(m_ps, c.scal + SC_PX_S, red);
+  block_max_to(m_xu, c.scal + SC_DXN_U, red); block_max_to(m_xs, c.scal + SC_DXN_S, red);
+  obj = block_sum(obj, red); qdx = block_sum(qdx, red);
+  if (threadIdx.x == 0) { c.part_s1[bid] = obj; c.part_s2[bid] = qdx; }
+}
+
+// Fixed-order final sums of the three partial arrays above (one workgroup).
+__global__ void __launch_bounds__(TB) k_final_sums(Ctx c) {
+  __shared__ double red[8];
+  double s[1];
+  reduce_parts<1>(c.part_s0, nullptr, nullptr, c.gridA, red, s);
+  if (threadIdx.x == 0) c.scal[SC_DYLHS] = s[0];
+  reduce_parts<1>(c.part_s1, nullptr, nullptr, c.gridM, red, s);
+  if (threadIdx.x == 0) c.scal[SC_OBJ] = s[0];
+  reduce_parts<1>(c.part_s2, nullptr, nullptr, c.gridM, red, s);
+  if (threadIdx.x == 0) c.scal[SC_QDX] = s[0];
+}
+
+// Second stage of the infeasibility tests (auxil.c:401-417, 456-497):
+// A' dy_proj, P dx over M; A dx row test over A.
+__global__ void __launch_bounds__(TB) k_certificates(Ctx c, double eps_dx, int unscaled) {
+  LDS_DECL(1);
+  const bool sc = c.prm->has_scaling && unscaled;
+  if ((int)blockIdx.x < c.gridA) {
+    double viol = 0;
+    for (int bi = blockIdx.x; bi < c.A.nblk; bi += c.gridA) {
+      const RowBlk b = c.A.blk[bi];
+      const bool longrow = (b.k1 - b.k0) > MAX_CHUNK;
+      if (!longrow) { stage_products<1>(c.A, b, c.dxy, nullptr, lprod, nullptr); __syncthreads(); }
+      for (int i = b.r0 + (longrow ? 0 : threadIdx.x); i < b.r1; i += (longrow ? 1 : TB)) {
+        double adx;
+        if (longrow) adx = long_row_dot(c.A, b.k0, b.k1, c.dxy, red);
+        else adx = row_sum(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0);
+        if (!longrow || threadIdx.x == 0) {
+          if (sc) adx = c.Einv[i] * adx;
+          if ((c.u[i] < INF_BOUND && adx > eps_dx) || (c.l[i] > -INF_BOUND && adx < -eps_dx)) viol += 1.0;
+        }
+      }
+      __syncthreads();
+    }
+    viol = block_sum(viol, red);
+    if (threadIdx.x == 0 && viol > 0) atomic_max_pos(c.scal + SC_ADX_VIOL, viol);
+    return;
+  }
+  const int bid = blockIdx.x - c.gridA;
+  double m_tu = 0, m_ts = 0, m_pu = 0, m_ps = 0;
+  for (int bi = bid; bi < c.M.nblk; bi += c.gridM) {
+    const RowBlk b = c.M.blk[bi];
+    const bool longrow = (b.k1 - b.k0) > MAX_CHUNK;
+    if (!longrow) { stage_products<1>(c.M, b, c.dxy, nullptr, lprod, nullptr); __syncthreads(); }
+    for (int j = b.r0 + (longrow ? 0 : threadIdx.x); j < b.r1; j += (longrow ? 1 : TB)) {
+      double pdx, atdy;
+      if (longrow) {
+        pdx  = long_row_dot(c.M, b.k0, c.M.split[j], c.dxy, red);
+        atdy = long_row_dot(c.M, c.M.split[j], b.k1, c.dxy, red);
+      } else {
+        const int a0 = c.M.rowptr[j] - b.k0, as = c.M.split[j] - b.k0, a1 = c.M.rowptr[j + 1] - b.k0;
+        pdx = row_sum(lprod, a0, as);
+        atdy = row_sum(lprod, as, a1);
+      }
+      if (!longrow || threadIdx.x == 0) {
+        const double di = sc ? c.Dinv[j] : 1.0;
+        m_tu = fmax(m_tu, fabs(di * atdy)); m_ts = fmax(m_ts, fabs(atdy));
+        m_pu = fmax(m_pu, fabs(di * pdx));  m_ps = fmax(m_ps, fabs(pdx));
+      }
+    }
+    __syncthreads();
+  }
+  block_max_to(m_tu, c.scal + SC_ATDY_U, red); block_max_to(m_ts, c.scal + SC_ATDY_S, red);
+  block_max_to(m_pu, c.scal + SC_PDX_U, red);  block_max_to(m_ps, c.scal + SC_PDX_S, red);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct HostMat {         // host image of a device CSR matrix
+  int nrows = 0, ncols = 0;
+  std::vector<int> rowptr, col, split;
+  std::vector<double> val;
+  std::vector<RowBlk> blk;
+  int *d_rowptr = nullptr, *d_col = nullptr, *d_split = nullptr;
+  double *d_val = nullptr;
+  RowBlk *d_blk = nullptr;
+};
+
+struct hipeng {
+  int device = 0;
+  int n = 0, m = 0;
+  hipStream_t stream = nullptr;
+  HostMat A, M;
+  std::vector<int> A_csc2csr;          // CSC slot of A -> CSR slot
+  std::vector<int> P_toM_up, P_toM_lo; // triu(P) slot -> slots in M (lo = -1 on the diagonal)
+  std::vector<int> A_toM;              // CSC slot of A -> slot in M
+  std::vector<double> pdiag;
+  Ctx c{};
+  Params prm{};
+  Params *d_prm = nullptr;
+  std::vector<void *> allocs;
+  std::map<int, hipGraphExec_t> graphs, cgraphs;
+  int K = 8;
+  bool calibrated = false;
+  hipeng_stats stats{};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  long long admm_done_seen = 0;
+};
+
+template <typename T>
+static int dev_alloc(hipeng *e, T **p, size_t count) {
+  void *q = nullptr;
+  if (count == 0) count = 1;
+  HIPCHK(hipMalloc(&q, count * sizeof(T)));
+  HIPCHK(hipMemsetAsync(q, 0, count * sizeof(T), e->stream));
+  e->allocs.push_back(q);
+  *p = static_cast<T *>(q);
+  return 0;
+}
+
+// Greedy row blocks: as many whole rows as fit `chunk` products (at least one
+// row; a single row may exceed MAX_CHUNK and then takes the long-row path).
+static void build_blocks(HostMat &H, int chunk) {
+  H.blk.clear();
+  int r = 0;
+  while (r < H.nrows) {
+    int r1 = r + 1;
+    const int k0 = H.rowptr[r];
+    while (r1 < H.nrows && H.rowptr[r1 + 1] - k0 <= chunk && (r1 - r) < 4 * TB) r1++;
+    H.blk.push_back({r, r1, k0, H.rowptr[r1]});
+    r = r1;
+  }
+}
+
+static int pick_chunk(long long nnz, int nrows) {
+  // enough workgroups to cover 256 CUs several times on small problems,
+  // full 2048-product chunks once the matrix is large
+  int chunk = MAX_CHUNK;
+  while (chunk > 256 && nnz / chunk < 1024) chunk >>= 1;
+  (void)nrows;
+  return chunk;
+}
+
+static int upload_mat(hipeng *e, HostMat &H) {
+  if (dev_alloc(e, &H.d_rowptr, H.rowptr.size())) return HIPENG_ERR_HIP;
+  if (dev_alloc(e, &H.d_col, H.col.size())) return HIPENG_ERR_HIP;
+  if (dev_alloc(e, &H.d_val, H.val.size())) return HIPENG_ERR_HIP;
+  if (dev_alloc(e, &H.d_blk, H.blk.size())) return HIPENG_ERR_HIP;
+  HIPCHK(hipMemcpyAsync(H.d_rowptr, H.rowptr.data(), H.rowptr.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  if (!H.col.empty()) {
+    HIPCHK(hipMemcpyAsync(H.d_col, H.col.data(), H.col.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(H.d_val, H.val.data(), H.val.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  }
+  if (!H.blk.empty())
+    HIPCHK(hipMemcpyAsync(H.d_blk, H.blk.data(), H.blk.size() * sizeof(RowBlk), hipMemcpyHostToDevice, e->stream));
+  if (!H.split.empty()) {
+    if (dev_alloc(e, &H.d_split, H.split.size())) return HIPENG_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(H.d_split, H.split.data(), H.split.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  }
+  return 0;
+}
+
+static DevMat dev_view(const HostMat &H) {
+  DevMat d;
+  d.nrows = H.nrows; d.nblk = (int)H.blk.size();
+  d.rowptr = H.d_rowptr; d.col = H.d_col; d.val = H.d_val; d.split = H.d_split; d.blk = H.d_blk;
+  return d;
+}
+
+// CSC (int64) -> CSR (int32) of A, columns ascending inside each row.
+static void build_A(hipeng *e, const csc *A) {
+  const int n = e->n, m = e->m;
+  const long long nnz = A->p[n];
+  HostMat &H = e->A;
+  H.nrows = m; H.ncols = n;
+  H.rowptr.assign(m + 1, 0);
+  for (long long k = 0; k < nnz; k++) H.rowptr[A->i[k] + 1]++;
+  for (int i = 0; i < m; i++) H.rowptr[i + 1] += H.rowptr[i];
+  H.col.assign(nnz, 0); H.val.assign(nnz, 0.0);
+  e->A_csc2csr.assign(nnz, 0);
+  std::vector<int> nxt(H.rowptr.begin(), H.rowptr.end() - 1);
+  for (int j = 0; j < n; j++)
+    for (long long k = A->p[j]; k < A->p[j + 1]; k++) {
+      const int dst = nxt[A->i[k]]++;
+      H.col[dst] = j; H.val[dst] = A->x[k];
+      e->A_csc2csr[k] = dst;
+    }
+  build_blocks(H, pick_chunk(nnz, m));
+}
+
+// Fused row matrix M = [P_full | A'] with the reference's summation order.
+static void build_M(hipeng *e, const csc *P, const csc *A) {
+  const int n = e->n;
+  const long long nnzP = P->p[n], nnzA = A->p[n];
+  HostMat &H = e->M;
+  H.nrows = n; H.ncols = n + e->m;
+  std::vector<int> up(n, 0), lo(n, 0);
+  for (int j = 0; j < n; j++)
+    for (long long k = P->p[j]; k < P->p[j + 1]; k++) {
+      const int i = (int)P->i[k];
+      up[i]++;                 // entry (i,j), j >= i : upper part of row i
+      if (i != j) lo[j]++;     // mirrored entry (j,i), i < j : lower part of row j
+    }
+  H.rowptr.assign(n + 1, 0); H.split.assign(n, 0);
+  for (int j = 0; j < n; j++) {
+    H.split[j] = H.rowptr[j] + up[j] + lo[j];
+    H.rowptr[j + 1] = H.split[j] + (int)(A->p[j + 1] - A->p[j]);
+  }
+  const long long tot = H.rowptr[n];
+  H.col.assign(tot, 0); H.val.assign(tot, 0.0);
+  e->P_toM_up.assign(nnzP, -1); e->P_toM_lo.assign(nnzP, -1); e->A_toM.assign(nnzA, -1);
+  e->pdiag.assign(n, 0.0);
+  std::vector<int> nu(n), nl(n);
+  for (int j = 0; j < n; j++) { nu[j] = H.rowptr[j]; nl[j] = H.rowptr[j] + up[j]; }
+  // scanning columns in ascending order fills each row's upper part in
+  // ascending column order; a column's own entries (ascending rows) fill the
+  // lower part of row j in ascending column order
+  for (int j = 0; j < n; j++)
+    for (long long k = P->p[j]; k < P->p[j + 1]; k++) {
+      const int i = (int)P->i[k];
+      int d = nu[i]++;
+      H.col[d] = j; H.val[d] = P->x[k]; e->P_toM_up[k] = d;
+      if (i != j) { d = nl[j]++; H.col[d] = i; H.val[d] = P->x[k]; e->P_toM_lo[k] = d; }
+      else e->pdiag[j] = P->x[k];
+    }
+  for (int j = 0; j < n; j++) {
+    int d = H.split[j];
+    for (long long k = A->p[j]; k < A->p[j + 1]; k++, d++) {
+      H.col[d] = n + (int)A->i[k]; H.val[d] = A->x[k]; e->A_toM[k] = d;
+    }
+  }
+  build_blocks(H, pick_chunk(tot, n));
+}
+
+static int upload_vec(hipeng *e, double *dst, const c_float *src, size_t cnt) {
+  if (cnt == 0 || !src) return 0;
+  HIPCHK(hipMemcpyAsync(dst, src, cnt * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  return 0;
+}
+
+static int push_params(hipeng *e) {
+  HIPCHK(hipMemcpyAsync(e->d_prm, &e->prm, sizeof(Params), hipMemcpyHostToDevice, e->stream));
+  // the source is host-pageable and may be reused right away
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+static int elem_grid(int cnt) {
+  int g = (cnt + TB - 1) / TB;
+  return std::max(1, std::min(g, MAX_PARTS));
+}
+
+extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_float *q,
+                             const c_float *l, const c_float *u, const c_float *rho_vec,
+                             const hipeng_params *prm, int device) {
+  if (!out || !P || !A || !prm) return HIPENG_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fprintf(stderr, "osqp_amd: no HIP device available -- the HIP engine has no CPU fallback\n");
+    return HIPENG_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) return HIPENG_ERR_ARG;
+  if (P->n > 0x7ffffff0LL || A->m > 0x7ffffff0LL || P->p[P->n] + A->p[A->n] + P->p[P->n] > 0x7ffffff0LL)
+    return HIPENG_ERR_ARG;   // int32 device indices
+  hipeng *e = new (std::nothrow) hipeng();
+  if (!e) return HIPENG_ERR_ALLOC;
+  e->device = device; e->n = (int)P->n; e->m = (int)A->m;
+  const int n = e->n, m = e->m;
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&e->ev0));
+  HIPCHK(hipEventCreate(&e->ev1));
+  build_A(e, A);
+  build_M(e, P, A);
+  if (upload_mat(e, e->A) || upload_mat(e, e->M)) return HIPENG_ERR_HIP;
+  Ctx &c = e->c;
+  c.n = n; c.m = m;
+  c.A = dev_view(e->A); c.M = dev_view(e->M);
+  c.gridM = std::min(MAX_PARTS, std::max(1, c.M.nblk));
+  c.gridA = std::min(MAX_PARTS, std::max(std::max(1, c.A.nblk), std::min(elem_grid(n), 256)));
+#define DA(field, cnt) if (dev_alloc(e, &c.field, (size_t)(cnt))) return HIPENG_ERR_HIP
+  DA(xy, n + m); DA(z, m); DA(zt, m); DA(va, n + m); DA(vb, n + m);
+  DA(q, n); DA(l, m); DA(u, m); DA(rho, m); DA(rhoinv, m); DA(minv, n); DA(pdiag, n);
+  DA(r, n); DA(zz, n); DA(kp, n); DA(pt0, n + m); DA(pt1, n + m);
+  DA(dxy, n + m); DA(dy, m); DA(cvec, n);
+  DA(D, n); DA(Dinv, n); DA(E, m); DA(Einv, m);
+  const int np = std::max(c.gridM, c.gridA);
+  DA(part_rz, np); DA(part_rr, np); DA(part_bb, np); DA(part_pkp, np);
+  DA(part_s0, np); DA(part_s1, np); DA(part_s2, np);
+  DA(scal, SC_COUNT);
+  DA(st, 1);
+#undef DA
+  if (dev_alloc(e, &e->d_prm, 1)) return HIPENG_ERR_HIP;
+  c.prm = e->d_prm;
+  e->prm.sigma = prm->sigma; e->prm.alpha = prm->alpha;
+  e->prm.eps_rel = prm->pcg_eps_rel; e->prm.eps_abs = prm->pcg_eps_abs;
+  e->prm.pcg_max_iter = (int)prm->pcg_max_iter; e->prm.cinv = 1.0;
+  e->prm.use_cvec = 0; e->prm.has_scaling = 0;
+  if (push_params(e)) return HIPENG_ERR_HIP;
+  if (upload_vec(e, c.q, q, n) || upload_vec(e, c.l, l, m) || upload_vec(e, c.u, u, m) ||
+      upload_vec(e, c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
+  e->stats.kernels_per_pcg_iter = 3;
+  *out = e;
+  if (rho_vec) { int rc = hipeng_upload_rho(e, rho_vec); if (rc) return rc; }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" void hipeng_destroy(hipeng *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.second);
+  for (auto &g : e->cgraphs) (void)hipGraphExecDestroy(g.second);
+  for (void *p : e->allocs) (void)hipFree(p);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+extern "C" int hipeng_sync(hipeng *e) {
+  if (!e) return HIPENG_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int hipeng_set_params(hipeng *e, const hipeng_params *prm) {
+  if (!e || !prm) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  const bool sigma_changed = prm->sigma != e->prm.sigma;
+  e->prm.sigma = prm->sigma; e->prm.alpha = prm->alpha;
+  e->prm.eps_rel = prm->pcg_eps_rel; e->prm.eps_abs = prm->pcg_eps_abs;
+  e->prm.pcg_max_iter = (int)prm->pcg_max_iter;
+  if (push_params(e)) return HIPENG_ERR_HIP;
+  if (sigma_changed) hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
+  return 0;
+}
+
+extern "C" int hipeng_set_scaling(hipeng *e, const c_float *D, const c_float *E, c_float cc) {
+  if (!e) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  if (D && (e->m == 0 || E)) {
+    std::vector<double> Di(e->n), Ei(e->m);
+    for (int j = 0; j < e->n; j++) Di[j] = 1.0 / D[j];
+    for (int i = 0; i < e->m; i++) Ei[i] = 1.0 / E[i];
+    if (upload_vec(e, e->c.D, D, e->n) || upload_vec(e, e->c.E, E, e->m) ||
+        upload_vec(e, e->c.Dinv, Di.data(), e->n) || upload_vec(e, e->c.Einv, Ei.data(), e->m))
+      return HIPENG_ERR_HIP;
+    e->prm.has_scaling = 1; e->prm.cinv = 1.0 / cc;
+    if (push_params(e)) return HIPENG_ERR_HIP;   // also fences the temporaries above
+  } else {
+    e->prm.has_scaling = 0; e->prm.cinv = 1.0;
+    if (push_params(e)) return HIPENG_ERR_HIP;
+  }
+  return 0;
+}
+
+extern "C" int hipeng_upload_q(hipeng *e, const c_float *q) {
+  if (!e || !q) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  if (upload_vec(e, e->c.q, q, e->n)) return HIPENG_ERR_HIP;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int hipeng_upload_bounds(hipeng *e, const c_float *l, const c_float *u) {
+  if (!e) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  if (upload_vec(e, e->c.l, l, e->m) || upload_vec(e, e->c.u, u, e->m)) return HIPENG_ERR_HIP;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int hipeng_upload_rho(hipeng *e, const c_float *rho_vec) {
+  if (!e) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  if (e->m > 0) {
+    if (!rho_vec) return HIPENG_ERR_ARG;
+    if (upload_vec(e, e->c.rho, rho_vec, e->m)) return HIPENG_ERR_HIP;
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c);
+  }
+  hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->calibrated = false;   // the PCG iteration count usually jumps after a rho change
+  return 0;
+}
+
+extern "C" int hipeng_upload_matrices(hipeng *e, const csc *P, const csc *A) {
+  if (!e || !P || !A) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  const int n = e->n;
+  if (P->p[n] != (long long)e->P_toM_up.size() || A->p[n] != (long long)e->A_toM.size())
+    return HIPENG_ERR_ARG;
+  for (long long k = 0; k < P->p[n]; k++) {
+    e->M.val[e->P_toM_up[k]] = P->x[k];
+    if (e->P_toM_lo[k] >= 0) e->M.val[e->P_toM_lo[k]] = P->x[k];
+  }
+  for (int j = 0; j < n; j++) {
+    e->pdiag[j] = 0.0;
+    for (long long k = P->p[j]; k < P->p[j + 1]; k++) if (P->i[k] == j) e->pdiag[j] = P->x[k];
+  }
+  for (long long k = 0; k < A->p[n]; k++) {
+    e->M.val[e->A_toM[k]] = A->x[k];
+    e->A.val[e->A_csc2csr[k]] = A->x[k];
+  }
+  if (upload_vec(e, e->M.d_val, e->M.val.data(), e->M.val.size()) ||
+      upload_vec(e, e->A.d_val, e->A.val.data(), e->A.val.size()) ||
+      upload_vec(e, e->c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
+  hipLaunchKernelGGL(k_precond, dim3(elem_grid(n)), dim3(TB), 0, e->stream, e->c);
+  // z~ = A x~ for the new A so that the PCG warm start stays consistent
+  if (e->m > 0) {
+    hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, e->c.va, e->c.zt, 0);
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int hipeng_cold_start(hipeng *e) {
+  if (!e) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  const size_t nm = (size_t)(e->n + e->m) * sizeof(double);
+  HIPCHK(hipMemsetAsync(e->c.xy, 0, std::max<size_t>(nm, 8), e->stream));
+  HIPCHK(hipMemsetAsync(e->c.va, 0, std::max<size_t>(nm, 8), e->stream));
+  HIPCHK(hipMemsetAsync(e->c.vb, 0, std::max<size_t>(nm, 8), e->stream));
+  HIPCHK(hipMemsetAsync(e->c.z, 0, std::max<size_t>(e->m, 1) * sizeof(double), e->stream));
+  HIPCHK(hipMemsetAsync(e->c.zt, 0, std::max<size_t>(e->m, 1) * sizeof(double), e->stream));
+  return 0;
+}
+
+extern "C" int hipeng_set_iterates(hipeng *e, const c_float *x, const c_float *y) {
+  if (!e) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  const int n = e->n, m = e->m;
+  if (y && upload_vec(e, e->c.xy + n, y, m)) return HIPENG_ERR_HIP;
+  if (x) {
+    if (upload_vec(e, e->c.xy, x, n)) return HIPENG_ERR_HIP;
+    // PCG warm start x~ = x ; z = A x ; z~ = z   (osqp_warm_start, osqp.c:960-963)
+    HIPCHK(hipMemcpyAsync(e->c.va, e->c.xy, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    if (m > 0) {
+      hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, e->c.xy, e->c.z, 0);
+      HIPCHK(hipMemcpyAsync(e->c.zt, e->c.z, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    }
+  }
+  if (m > 0) hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int hipeng_set_z(hipeng *e, const c_float *z) {
+  if (!e) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  const int m = e->m;
+  if (m > 0 && z) {
+    if (upload_vec(e, e->c.z, z, m)) return HIPENG_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(e->c.zt, e->c.z, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+// ---- graphs ---------------------------------------------------------------
+static void launch_pcg_iter(hipeng *e, int it, int flags) {
+  const Ctx &c = e->c;
+  hipLaunchKernelGGL(k_pcg_Ap, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, flags);
+  hipLaunchKernelGGL(k_pcg_Kp, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags & 4);
+  hipLaunchKernelGGL(k_pcg_update, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags & 4);
+}
+
+static int get_graph(hipeng *e, int K, bool cont, hipGraphExec_t *out) {
+  auto &cache = cont ? e->cgraphs : e->graphs;
+  auto f = cache.find(K);
+  if (f != cache.end()) { *out = f->second; return 0; }
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+  if (!cont) {
+    hipLaunchKernelGGL(k_pcg_init, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c);
+    for (int it = 0; it < K; it++) launch_pcg_iter(e, it, it == 0 ? 1 : 0);
+  } else {
+    // resumes at an even iteration index (K is always even): parity of the
+    // p / rz ping-pong buffers is preserved
+    for (int it = 0; it < K; it++) launch_pcg_iter(e, it + 2, it == 0 ? 2 : 0);
+  }
+  hipLaunchKernelGGL(k_admm_finalize, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c);
+  HIPCHK(hipStreamEndCapture(e->stream, &g));
+  HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  HIPCHK(hipGraphDestroy(g));
+  cache[K] = ge;
+  *out = ge;
+  return 0;
+}
+
+static int read_state(hipeng *e, State *s) {
+  HIPCHK(hipMemcpyAsync(s, e->c.st, sizeof(State), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+static int next_K(int want, int cap) {
+  int K = 2;
+  while (K < want) K = (K < 16) ? K + 2 : (K < 64 ? K + 8 : K * 2);
+  if (K > cap) K = std::max(2, (cap + 1) & ~1);
+  return K;
+}
+
+extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
+  if (!e || count < 0) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  State s;
+  // reset the per-call maximum
+  if (read_state(e, &s)) return HIPENG_ERR_HIP;
+  s.iters_max = 0;
+  HIPCHK(hipMemcpyAsync(e->c.st, &s, sizeof(State), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const long long start = s.admm_done;
+  long long remaining = count;
+  const int cap = std::max(2, e->prm.pcg_max_iter);
+  int guard = 0;
+  while (remaining > 0) {
+    hipGraphExec_t ge;
+    if (get_graph(e, e->K, false, &ge)) return HIPENG_ERR_HIP;
+    const long long burst = e->calibrated ? std::min<long long>(remaining, 64) : 1;
+    e->calibrated = true;
+    for (long long i = 0; i < burst; i++) HIPCHK(hipGraphLaunch(ge, e->stream));
+    e->stats.graph_launches += (c_int)burst;
+    if (read_state(e, &s)) return HIPENG_ERR_HIP;
+    while (s.stalled) {            // finish the stalled solve with more PCG iterations
+      hipGraphExec_t gc;
+      const int Kc = next_K(std::max(e->K, 4), cap);
+      if (get_graph(e, Kc, true, &gc)) return HIPENG_ERR_HIP;
+      HIPCHK(hipGraphLaunch(gc, e->stream));
+      e->stats.graph_launches += 1;
+      if (read_state(e, &s)) return HIPENG_ERR_HIP;
+      e->K = next_K(std::max(e->K + 2, (int)(1.5 * std::max(s.iters[0], s.iters[1])) + 2), cap);
+      if (++guard > 100000) { fprintf(stderr, "osqp_amd: PCG continuation did not terminate\n"); return HIPENG_ERR_HIP; }
+    }
+    remaining = count - (s.admm_done - start);
+    // track the iteration count: shrink slowly, grow at once
+    const int want = (int)(1.25 * s.iters_max) + 2;
+    const int Kn = next_K(want, cap);
+    if (Kn > e->K || Kn < e->K - 4 || (Kn < e->K && e->K <= 16)) e->K = Kn;
+    if (++guard > 1000000) return HIPENG_ERR_HIP;
+  }
+  e->stats.admm_done = (c_int)(s.admm_done - start);
+  e->stats.pcg_iters_total = (c_int)s.iters_total;
+  e->stats.pcg_iters_last = s.iters_last;
+  e->stats.pcg_iters_max = s.iters_max;
+  e->stats.pcg_forced = s.forced;
+  return 0;
+}
+
+extern "C" int hipeng_get_stats(hipeng *e, hipeng_stats *st) {
+  if (!e || !st) return HIPENG_ERR_ARG;
+  *st = e->stats;
+  return 0;
+}
+
+// ---- residual scalars -----------------------------------------------------
+static void fill_scalars(const double *h, hipeng_scalars *o) {
+  o->pri_res_u = h[SC_PRI_U]; o->pri_res_s = h[SC_PRI_S];
+  o->z_u = h[SC_Z_U]; o->z_s = h[SC_Z_S]; o->Ax_u = h[SC_AX_U]; o->Ax_s = h[SC_AX_S];
+  o->dua_res_u = h[SC_DUA_U]; o->dua_res_s = h[SC_DUA_S];
+  o->q_u = h[SC_Q_U]; o->q_s = h[SC_Q_S]; o->Aty_u = h[SC_ATY_U]; o->Aty_s = h[SC_ATY_S];
+  o->Px_u = h[SC_PX_U]; o->Px_s = h[SC_PX_S];
+  o->obj_scaled = h[SC_OBJ];
+  o->dy_norm_u = h[SC_DYN_U]; o->dy_norm_s = h[SC_DYN_S]; o->dy_lhs = h[SC_DYLHS];
+  o->dx_norm_u = h[SC_DXN_U]; o->dx_norm_s = h[SC_DXN_S]; o->q_dx = h[SC_QDX];
+  o->Atdy_u = h[SC_ATDY_U]; o->Atdy_s = h[SC_ATDY_S];
+  o->Pdx_u = h[SC_PDX_U]; o->Pdx_s = h[SC_PDX_S];
+  o->Adx_viol = h[SC_ADX_VIOL];
+}
+
+extern "C" int hipeng_residuals(hipeng *e, hipeng_scalars *out) {
+  if (!e || !out) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipMemsetAsync(e->c.scal, 0, SC_COUNT * sizeof(double), e->stream));
+  hipLaunchKernelGGL(k_residuals, dim3(e->c.gridA + e->c.gridM), dim3(TB), 0, e->stream, e->c);
+  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(TB), 0, e->stream, e->c);
+  HIPCHK(hipGetLastError());
+  double h[SC_COUNT];
+  HIPCHK(hipMemcpyAsync(h, e->c.scal, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  fill_scalars(h, out);
+  return 0;
+}
+
+extern "C" int hipeng_certificates(hipeng *e, c_float eps_dx, int unscaled, hipeng_scalars *io) {
+  if (!e || !io) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipMemsetAsync(e->c.scal + SC_ATDY_U, 0, 5 * sizeof(double), e->stream));
+  hipLaunchKernelGGL(k_certificates, dim3(e->c.gridA + e->c.gridM), dim3(TB), 0, e->stream, e->c,
+                     (double)eps_dx, unscaled);
+  HIPCHK(hipGetLastError());
+  double h[SC_COUNT];
+  HIPCHK(hipMemcpyAsync(h, e->c.scal, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  io->Atdy_u = h[SC_ATDY_U]; io->Atdy_s = h[SC_ATDY_S];
+  io->Pdx_u = h[SC_PDX_U]; io->Pdx_s = h[SC_PDX_S]; io->Adx_viol = h[SC_ADX_VIOL];
+  return 0;
+}
+
+extern "C" int hipeng_download(hipeng *e, c_float *x, c_float *y, c_float *z, c_float *dx,
+                               c_float *dy, int dy_projected) {
+  if (!e) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  const size_t n = e->n, m = e->m;
+  if (x && n) HIPCHK(hipMemcpyAsync(x, e->c.xy, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (y && m) HIPCHK(hipMemcpyAsync(y, e->c.xy + n, m * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (z && m) HIPCHK(hipMemcpyAsync(z, e->c.z, m * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (dx && n) HIPCHK(hipMemcpyAsync(dx, e->c.dxy, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (dy && m) HIPCHK(hipMemcpyAsync(dy, dy_projected ? e->c.dxy + n : e->c.dy, m * sizeof(double),
+                                     hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+// ---- plugin-boundary solve --------------------------------------------------
+extern "C" int hipeng_kkt_solve(hipeng *e, c_float *b) {
+  if (!e || !b) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  const int n = e->n, m = e->m;
+  // reduced right-hand side: cvec = b1, vb(m-part) = rho . b2 ; start from x~ = 0
+  if (hipeng_cold_start(e)) return HIPENG_ERR_HIP;
+  if (upload_vec(e, e->c.cvec, b, n)) return HIPENG_ERR_HIP;
+  if (m > 0) {
+    // stage b2 in z, y = 0  =>  k_refresh_m writes vb = rho*z - y = rho.b2
+    if (upload_vec(e, e->c.z, b + n, m)) return HIPENG_ERR_HIP;
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c);
+  }
+  e->prm.use_cvec = 1;
+  if (push_params(e)) return HIPENG_ERR_HIP;
+  int rc = hipeng_run_admm(e, 1);
+  e->prm.use_cvec = 0;
+  if (push_params(e)) return HIPENG_ERR_HIP;
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(b, e->c.va, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (m > 0) HIPCHK(hipMemcpyAsync(b + n, e->c.zt, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+// ---- kernel-level entry points for tests and the roofline measurement -------
+extern "C" int hipeng_spmv(hipeng *e, int which, const c_float *x, c_float *y) {
+  if (!e || !x || !y || which < 0 || which > 2) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  const int n = e->n, m = e->m;
+  double *in = e->c.pt0, *out = e->c.pt1;   // scratch of n+m doubles each
+  HIPCHK(hipMemsetAsync(in, 0, (size_t)std::max(1, n + m) * sizeof(double), e->stream));
+  if (which == 0) {
+    if (upload_vec(e, in, x, n)) return HIPENG_ERR_HIP;
+    hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, in, out, 0);
+    HIPCHK(hipMemcpyAsync(y, out, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  } else {
+    if (which == 1) { if (upload_vec(e, in + n, x, m)) return HIPENG_ERR_HIP; }
+    else if (upload_vec(e, in, x, n)) return HIPENG_ERR_HIP;
+    hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.M.nblk))), dim3(TB), 0, e->stream, e->c.M, in, out,
+                       which == 1 ? 2 : 1);
+    HIPCHK(hipMemcpyAsync(y, out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) {
+  if (!e || !usec || reps <= 0 || which < 0 || which > 2) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  const Ctx &c = e->c;
+  auto one = [&](int it) {
+    if (which == 0) hipLaunchKernelGGL(k_pcg_Ap, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, 4);
+    else if (which == 1) hipLaunchKernelGGL(k_pcg_Kp, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, 4);
+    else hipLaunchKernelGGL(k_pcg_update, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, 4);
+  };
+  for (int i = 0; i < 10; i++) one(i);
+  HIPCHK(hipEventRecord(e->ev0, e->stream));
+  for (int i = 0; i < reps; i++) one(i);
+  HIPCHK(hipEventRecord(e->ev1, e->stream));
+  HIPCHK(hipEventSynchronize(e->ev1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  *usec = 1e3 * (double)ms / reps;
+  return 0;
+}
+
+extern "C" int hipeng_kernel_bytes(hipeng *e, int which, double *bytes) {
+  if (!e || !bytes) return HIPENG_ERR_ARG;
+  const double n = e->n, m = e->m;
+  const double nnzA = (double)e->A.val.size(), nnzM = (double)e->M.val.size();
+  // device layout: fp64 values + int32 indices (12 B per stored entry), one
+  // int32 row pointer per row, fp64 vectors; gathers counted once per vector
+  if (which == 0)       *bytes = nnzA * 12 + (m + 1) * 4 + 8 * (3 * n + 2 * m);   // zz,p_old -> p_new ; rho -> t
+  else if (which == 1)  *bytes = nnzM * 12 + (n + 1) * 4 + 8 * ((n + m) + n);     // [p|t] -> Kp
+  else                  *bytes = 8 * (7 * n);                                     // x~,r,Kp,p,Minv -> x~,r,zz
+  return 0;
+}

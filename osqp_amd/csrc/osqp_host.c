@@ -1,0 +1,1149 @@
+/*
+ * osqp_host.c -- host side (plain C) of the MI355X-native OSQP drop-in.
+ *
+ * Implements the reference's public API (include/osqp.h) on top of the HIP
+ * engine's C-ABI shim (include/osqp_amd_engine.h).  What stays on the host is
+ * what the reference does once per setup / per termination check on scalars:
+ * validation (src/auxil.c:791-1065), Ruiz equilibration at setup and on matrix
+ * updates (src/scaling.c:44-175), constraint classification for rho
+ * (src/auxil.c:76-142), the status decision of check_termination on the
+ * device-reduced scalars (src/auxil.c:681-786), rho adaptation
+ * (src/auxil.c:13-74) and bookkeeping.  Every per-iteration vector operation,
+ * SpMV and reduction runs on the GPU; nothing here falls back to CPU numerics
+ * for the hot path.
+ *
+ * The solve loop runs the device in windows that end at the next event the
+ * reference would act on (termination check, rho adaptation, print, max_iter),
+ * so info->iter and the iterate trajectory are the reference's.
+ * Documented deviations:
+ *   - adaptive_rho_interval == 0 uses the reference's non-PROFILING rule
+ *     (osqp.c:267-279) instead of wall-clock (osqp.c:453-485), SURVEY.md F5;
+ *   - time_limit and the window cap are polled between windows (<= 8 iterations
+ *     when a time limit is set), not every iteration (osqp.c:387-407);
+ *   - no SIGINT handler is installed.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <time.h>
+#include "../../include/osqp_amd.h"
+#include "../../include/osqp_amd_engine.h"
+
+#define HMAX(a, b) (((a) > (b)) ? (a) : (b))
+#define HMIN(a, b) (((a) < (b)) ? (a) : (b))
+#define BOUND_INF (OSQP_INFTY * MIN_SCALING)
+
+struct OSQP_TIMER { double t0; };
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void tic(OSQPTimer *t) { t->t0 = now_s(); }
+static double toc(const OSQPTimer *t) { return now_s() - t->t0; }
+
+/* ------------------------------------------------------------------------ */
+/* process-wide engine options (side channel, see include/osqp_amd.h)        */
+/* ------------------------------------------------------------------------ */
+static osqp_amd_options g_opt;
+static int g_opt_init = 0;
+
+static void opt_init(void) {
+  if (g_opt_init) return;
+  const char *s;
+  g_opt.pcg_eps_rel = 1e-10; g_opt.pcg_eps_abs = 1e-15; g_opt.pcg_max_iter = 0; g_opt.device = 0;
+  if ((s = getenv("OSQP_AMD_PCG_EPS_REL")))  g_opt.pcg_eps_rel = atof(s);
+  if ((s = getenv("OSQP_AMD_PCG_EPS_ABS")))  g_opt.pcg_eps_abs = atof(s);
+  if ((s = getenv("OSQP_AMD_PCG_MAX_ITER"))) g_opt.pcg_max_iter = atoll(s);
+  if ((s = getenv("OSQP_AMD_DEVICE")))       g_opt.device = atoll(s);
+  else if ((s = getenv("LOCAL_RANK")))       g_opt.device = atoll(s);   /* one process per GPU */
+  g_opt_init = 1;
+}
+void osqp_amd_get_options(osqp_amd_options *o) { opt_init(); *o = g_opt; }
+void osqp_amd_set_options(const osqp_amd_options *o) { opt_init(); g_opt = *o; }
+
+static void fill_params(hipeng_params *p, c_float sigma, c_float alpha, c_int n) {
+  opt_init();
+  p->sigma = sigma; p->alpha = alpha;
+  p->pcg_eps_rel = g_opt.pcg_eps_rel; p->pcg_eps_abs = g_opt.pcg_eps_abs;
+  p->pcg_max_iter = g_opt.pcg_max_iter > 0 ? g_opt.pcg_max_iter : HMAX(1000, 2 * n);
+}
+
+/* ------------------------------------------------------------------------ */
+/* the plugin object (vtable prefix + private part)                           */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  enum linsys_solver_type type;
+  c_int (*solve)(LinSysSolver *self, c_float *b);
+  void  (*free)(LinSysSolver *self);
+  c_int (*update_matrices)(LinSysSolver *self, const csc *P, const csc *A);
+  c_int (*update_rho_vec)(LinSysSolver *self, const c_float *rho_vec);
+  c_int nthreads;
+  /* private */
+  hipeng *eng;            /* device engine (owned)                                */
+  hipeng *aux;            /* workspace view only: lazily created solve() engine   */
+  OSQPWorkspace *owner;   /* non-NULL when this is a workspace's solver           */
+  c_int n, m, polish;
+  c_float sigma;
+  c_float *rho_tmp;       /* polish: constant 1/delta vector                      */
+  hipeng_scalars sc;      /* last residual scalars                                */
+  c_int sc_iter;          /* iteration they belong to (-1 = stale)                */
+  c_int host_syncs;
+} hip_pcg_solver;
+
+#define PCG(work) ((hip_pcg_solver *)((work)->linsys_solver))
+
+static c_int pcg_solve(LinSysSolver *self, c_float *b) {
+  hip_pcg_solver *s = (hip_pcg_solver *)self;
+  hipeng *e = s->eng;
+  if (s->owner) {   /* never disturb the workspace's resident iterates */
+    if (!s->aux) {
+      const OSQPWorkspace *w = s->owner;
+      hipeng_params prm;
+      fill_params(&prm, w->settings->sigma, w->settings->alpha, w->data->n);
+      opt_init();
+      if (hipeng_create(&s->aux, w->data->P, w->data->A, NULL, NULL, NULL, w->rho_vec, &prm,
+                        (int)g_opt.device)) return 1;
+    }
+    e = s->aux;
+  }
+  if (hipeng_kkt_solve(e, b)) return 1;
+  if (s->polish) {   /* return [x ; nu] with nu = (A x - b2)/delta  (qdldl_interface.c:354-356) */
+    /* kkt_solve wrote z~ = A x into b[n..]; the caller's b2 is kept in rho_tmp[m..2m) */
+    for (c_int i = 0; i < s->m; i++) b[s->n + i] = (b[s->n + i] - s->rho_tmp[s->m + i]) / s->sigma;
+  }
+  return 0;
+}
+
+static c_int pcg_solve_polish(LinSysSolver *self, c_float *b) {
+  hip_pcg_solver *s = (hip_pcg_solver *)self;
+  for (c_int i = 0; i < s->m; i++) s->rho_tmp[s->m + i] = b[s->n + i];
+  return pcg_solve(self, b);
+}
+
+static void pcg_free(LinSysSolver *self) {
+  hip_pcg_solver *s = (hip_pcg_solver *)self;
+  if (!s) return;
+  hipeng_destroy(s->eng);
+  hipeng_destroy(s->aux);
+  free(s->rho_tmp);
+  free(s);
+}
+
+static c_int pcg_update_matrices(LinSysSolver *self, const csc *P, const csc *A) {
+  hip_pcg_solver *s = (hip_pcg_solver *)self;
+  if (hipeng_upload_matrices(s->eng, P, A)) return 1;
+  if (s->aux && hipeng_upload_matrices(s->aux, P, A)) return 1;
+  s->sc_iter = -1;
+  return 0;
+}
+
+static c_int pcg_update_rho_vec(LinSysSolver *self, const c_float *rho_vec) {
+  hip_pcg_solver *s = (hip_pcg_solver *)self;
+  if (hipeng_upload_rho(s->eng, rho_vec)) return 1;
+  if (s->aux && hipeng_upload_rho(s->aux, rho_vec)) return 1;
+  return 0;
+}
+
+static hip_pcg_solver *pcg_alloc(c_int n, c_int m, c_float sigma, c_int polish) {
+  hip_pcg_solver *s = (hip_pcg_solver *)calloc(1, sizeof(hip_pcg_solver));
+  if (!s) return NULL;
+  s->type = HIP_PCG_SOLVER; s->nthreads = 1;
+  s->solve = polish ? pcg_solve_polish : pcg_solve;
+  s->free = pcg_free;
+  s->update_matrices = pcg_update_matrices; s->update_rho_vec = pcg_update_rho_vec;
+  s->n = n; s->m = m; s->sigma = sigma; s->polish = polish; s->sc_iter = -1;
+  return s;
+}
+
+/* Stand-alone plugin constructor (lin_sys/direct/qdldl/qdldl_interface.c:177-323
+ * is the CPU counterpart).  polish != 0: sigma carries delta, rho_vec is NULL,
+ * and the (2,2) block is -delta I  =>  reduced system with rho = 1/delta. */
+c_int init_linsys_solver_hip_pcg(LinSysSolver **sp, const csc *P, const csc *A,
+                                 c_float sigma, const c_float *rho_vec, c_int polish) {
+  if (!sp || !P || !A) return OSQP_LINSYS_SOLVER_INIT_ERROR;
+  *sp = NULL;
+  hip_pcg_solver *s = pcg_alloc(P->n, A->m, sigma, polish);
+  if (!s) return OSQP_LINSYS_SOLVER_INIT_ERROR;
+  const c_float *rv = rho_vec;
+  if (polish) {
+    s->rho_tmp = (c_float *)malloc((size_t)(2 * A->m + 1) * sizeof(c_float));
+    if (!s->rho_tmp) { free(s); return OSQP_LINSYS_SOLVER_INIT_ERROR; }
+    for (c_int i = 0; i < A->m; i++) s->rho_tmp[i] = 1.0 / sigma;
+    rv = s->rho_tmp;
+  }
+  hipeng_params prm;
+  fill_params(&prm, sigma, 1.0, P->n);
+  if (polish) { prm.pcg_eps_rel = HMIN(prm.pcg_eps_rel, 1e-12); }
+  opt_init();
+  if (hipeng_create(&s->eng, P, A, NULL, NULL, NULL, rv, &prm, (int)g_opt.device)) {
+    free(s->rho_tmp); free(s);
+    return OSQP_LINSYS_SOLVER_INIT_ERROR;
+  }
+  *sp = (LinSysSolver *)s;
+  return 0;
+}
+
+c_int load_linsys_solver(enum linsys_solver_type t)   { (void)t; return 0; }
+c_int unload_linsys_solver(enum linsys_solver_type t) { (void)t; return 0; }
+
+/* Every id is served by the HIP PCG plugin: this library carries no CPU
+ * factorisation (lin_sys.c:56-75 is the reference dispatch). */
+c_int init_linsys_solver(LinSysSolver **s, const csc *P, const csc *A, c_float sigma,
+                         const c_float *rho_vec, enum linsys_solver_type t, c_int polish) {
+  (void)t;
+  return init_linsys_solver_hip_pcg(s, P, A, sigma, rho_vec, polish);
+}
+
+/* ------------------------------------------------------------------------ */
+/* small host helpers                                                         */
+/* ------------------------------------------------------------------------ */
+static c_float *dup_vec(const c_float *a, c_int n) {
+  c_float *b = (c_float *)malloc((size_t)(n > 0 ? n : 1) * sizeof(c_float));
+  if (b && n > 0) memcpy(b, a, (size_t)n * sizeof(c_float));
+  return b;
+}
+static c_float *zero_vec(c_int n) { return (c_float *)calloc((size_t)(n > 0 ? n : 1), sizeof(c_float)); }
+
+static csc *dup_csc(const csc *A) {
+  c_int nnz = A->p[A->n];
+  csc *B = (csc *)calloc(1, sizeof(csc));
+  if (!B) return NULL;
+  B->m = A->m; B->n = A->n; B->nz = -1; B->nzmax = nnz > 0 ? nnz : 1;
+  B->p = (c_int *)malloc((size_t)(A->n + 1) * sizeof(c_int));
+  B->i = (c_int *)malloc((size_t)B->nzmax * sizeof(c_int));
+  B->x = (c_float *)malloc((size_t)B->nzmax * sizeof(c_float));
+  if (!B->p || !B->i || !B->x) { free(B->p); free(B->i); free(B->x); free(B); return NULL; }
+  memcpy(B->p, A->p, (size_t)(A->n + 1) * sizeof(c_int));
+  if (nnz > 0) {
+    memcpy(B->i, A->i, (size_t)nnz * sizeof(c_int));
+    memcpy(B->x, A->x, (size_t)nnz * sizeof(c_float));
+  }
+  return B;
+}
+static void free_csc(csc *A) { if (A) { free(A->p); free(A->i); free(A->x); free(A); } }
+
+csc *csc_matrix(c_int m, c_int n, c_int nzmax, c_float *x, c_int *i, c_int *p) {
+  csc *M = (csc *)malloc(sizeof(csc));
+  if (!M) return NULL;
+  M->m = m; M->n = n; M->nz = -1; M->nzmax = nzmax; M->x = x; M->i = i; M->p = p;
+  return M;
+}
+
+static c_float absmax(const c_float *v, c_int n) {
+  c_float b = 0.0;
+  for (c_int k = 0; k < n; k++) { c_float a = fabs(v[k]); if (a > b) b = a; }
+  return b;
+}
+
+/* ------------------------------------------------------------------------ */
+/* status strings (src/auxil.c:651-679)                                       */
+/* ------------------------------------------------------------------------ */
+static void put_status(OSQPInfo *info, c_int v) {
+  static const struct { c_int v; const char *s; } T[] = {
+    {OSQP_SOLVED, "solved"}, {OSQP_SOLVED_INACCURATE, "solved inaccurate"},
+    {OSQP_PRIMAL_INFEASIBLE, "primal infeasible"},
+    {OSQP_PRIMAL_INFEASIBLE_INACCURATE, "primal infeasible inaccurate"},
+    {OSQP_UNSOLVED, "unsolved"}, {OSQP_DUAL_INFEASIBLE, "dual infeasible"},
+    {OSQP_DUAL_INFEASIBLE_INACCURATE, "dual infeasible inaccurate"},
+    {OSQP_MAX_ITER_REACHED, "maximum iterations reached"},
+    {OSQP_TIME_LIMIT_REACHED, "run time limit reached"},
+    {OSQP_SIGINT, "interrupted"}, {OSQP_NON_CVX, "problem non convex"}};
+  info->status_val = v;
+  for (size_t k = 0; k < sizeof(T) / sizeof(T[0]); k++)
+    if (T[k].v == v) { snprintf(info->status, sizeof(info->status), "%s", T[k].s); return; }
+}
+
+static c_int solution_exists(const OSQPInfo *info) {
+  c_int v = info->status_val;
+  return !(v == OSQP_PRIMAL_INFEASIBLE || v == OSQP_PRIMAL_INFEASIBLE_INACCURATE ||
+           v == OSQP_DUAL_INFEASIBLE || v == OSQP_DUAL_INFEASIBLE_INACCURATE || v == OSQP_NON_CVX);
+}
+
+static void info_reset(OSQPInfo *info) {   /* src/auxil.c:632-649 */
+  info->solve_time = 0.0; info->polish_time = 0.0;
+  put_status(info, OSQP_UNSOLVED);
+  info->rho_updates = 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* defaults and validation                                                    */
+/* ------------------------------------------------------------------------ */
+void osqp_set_default_settings(OSQPSettings *s) {   /* src/osqp.c:24-71 */
+  s->rho = RHO; s->sigma = SIGMA; s->scaling = SCALING;
+  s->adaptive_rho = ADAPTIVE_RHO; s->adaptive_rho_interval = ADAPTIVE_RHO_INTERVAL;
+  s->adaptive_rho_tolerance = ADAPTIVE_RHO_TOLERANCE; s->adaptive_rho_fraction = ADAPTIVE_RHO_FRACTION;
+  s->max_iter = MAX_ITER; s->eps_abs = EPS_ABS; s->eps_rel = EPS_REL;
+  s->eps_prim_inf = EPS_PRIM_INF; s->eps_dual_inf = EPS_DUAL_INF; s->alpha = ALPHA;
+  s->linsys_solver = HIP_PCG_SOLVER;
+  s->delta = DELTA; s->polish = POLISH; s->polish_refine_iter = POLISH_REFINE_ITER;
+  s->verbose = VERBOSE; s->scaled_termination = SCALED_TERMINATION;
+  s->check_termination = CHECK_TERMINATION; s->warm_start = WARM_START; s->time_limit = TIME_LIMIT;
+}
+
+#define FAIL(msg) do { fprintf(stderr, "ERROR in %s: %s\n", __func__, msg); return 1; } while (0)
+
+static c_int check_data(const OSQPData *d) {   /* src/auxil.c:791-879 */
+  if (!d) FAIL("Missing data");
+  if (!d->P) FAIL("Missing matrix P");
+  if (!d->A) FAIL("Missing matrix A");
+  if (!d->q) FAIL("Missing vector q");
+  if (d->n <= 0 || d->m < 0) FAIL("n must be positive and m nonnegative");
+  if (d->P->m != d->n) FAIL("P does not have dimension n x n");
+  if (d->P->m != d->P->n) FAIL("P is not square");
+  for (c_int j = 0; j < d->n; j++)
+    for (c_int k = d->P->p[j]; k < d->P->p[j + 1]; k++)
+      if (d->P->i[k] > j) FAIL("P is not upper triangular");
+  if (d->A->m != d->m || d->A->n != d->n) FAIL("A does not have dimension m x n");
+  for (c_int i = 0; i < d->m; i++)
+    if (d->l[i] > d->u[i]) FAIL("Lower bound is greater than upper bound");
+  return 0;
+}
+
+static c_int check_settings(const OSQPSettings *s) {   /* src/auxil.c:893-1065 */
+  if (!s) FAIL("Missing settings!");
+  if (s->scaling < 0) FAIL("scaling must be nonnegative");
+  if (s->adaptive_rho != 0 && s->adaptive_rho != 1) FAIL("adaptive_rho must be either 0 or 1");
+  if (s->adaptive_rho_interval < 0) FAIL("adaptive_rho_interval must be nonnegative");
+  if (s->adaptive_rho_fraction <= 0) FAIL("adaptive_rho_fraction must be positive");
+  if (s->adaptive_rho_tolerance < 1.0) FAIL("adaptive_rho_tolerance must be >= 1");
+  if (s->polish_refine_iter < 0) FAIL("polish_refine_iter must be nonnegative");
+  if (s->rho <= 0.0) FAIL("rho must be positive");
+  if (s->sigma <= 0.0) FAIL("sigma must be positive");
+  if (s->delta <= 0.0) FAIL("delta must be positive");
+  if (s->max_iter <= 0) FAIL("max_iter must be positive");
+  if (s->eps_abs < 0.0) FAIL("eps_abs must be nonnegative");
+  if (s->eps_rel < 0.0) FAIL("eps_rel must be nonnegative");
+  if (s->eps_rel == 0.0 && s->eps_abs == 0.0) FAIL("at least one of eps_abs and eps_rel must be positive");
+  if (s->eps_prim_inf <= 0.0) FAIL("eps_prim_inf must be positive");
+  if (s->eps_dual_inf <= 0.0) FAIL("eps_dual_inf must be positive");
+  if (s->alpha <= 0.0 || s->alpha >= 2.0) FAIL("alpha must be strictly between 0 and 2");
+  if (s->linsys_solver != QDLDL_SOLVER && s->linsys_solver != MKL_PARDISO_SOLVER &&
+      s->linsys_solver != HIP_PCG_SOLVER) FAIL("linsys_solver not recognized");
+  if (s->verbose != 0 && s->verbose != 1) FAIL("verbose must be either 0 or 1");
+  if (s->scaled_termination != 0 && s->scaled_termination != 1) FAIL("scaled_termination must be either 0 or 1");
+  if (s->check_termination < 0) FAIL("check_termination must be nonnegative");
+  if (s->warm_start != 0 && s->warm_start != 1) FAIL("warm_start must be either 0 or 1");
+  if (s->time_limit < 0.0) FAIL("time_limit must be nonnegative");
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Ruiz equilibration on the host copy of the data (src/scaling.c:7-175)      */
+/* ------------------------------------------------------------------------ */
+static void clip_scale(c_float *v, c_int n) {
+  for (c_int k = 0; k < n; k++) {
+    if (v[k] < MIN_SCALING) v[k] = 1.0;
+    if (v[k] > MAX_SCALING) v[k] = MAX_SCALING;
+  }
+}
+
+static void sym_col_norms(const csc *P, c_float *out) {
+  for (c_int j = 0; j < P->n; j++) out[j] = 0.0;
+  for (c_int j = 0; j < P->n; j++)
+    for (c_int k = P->p[j]; k < P->p[j + 1]; k++) {
+      c_float a = fabs(P->x[k]);
+      c_int i = P->i[k];
+      if (a > out[j]) out[j] = a;
+      if (i != j && a > out[i]) out[i] = a;
+    }
+}
+
+static void equilibrate(OSQPWorkspace *w) {
+  c_int n = w->data->n, m = w->data->m;
+  csc *P = w->data->P, *A = w->data->A;
+  c_float *q = w->data->q, *D = w->scaling->D, *E = w->scaling->E;
+  c_float *dn = w->D_temp, *da = w->D_temp_A, *en = w->E_temp;
+  w->scaling->c = 1.0;
+  for (c_int j = 0; j < n; j++) D[j] = 1.0;
+  for (c_int i = 0; i < m; i++) E[i] = 1.0;
+  for (c_int pass = 0; pass < w->settings->scaling; pass++) {
+    sym_col_norms(P, dn);
+    for (c_int i = 0; i < m; i++) en[i] = 0.0;
+    for (c_int j = 0; j < n; j++) {
+      c_float cmax = 0.0;
+      for (c_int k = A->p[j]; k < A->p[j + 1]; k++) {
+        c_float a = fabs(A->x[k]);
+        if (a > cmax) cmax = a;
+        if (a > en[A->i[k]]) en[A->i[k]] = a;
+      }
+      da[j] = cmax;
+      if (cmax > dn[j]) dn[j] = cmax;
+    }
+    clip_scale(dn, n); clip_scale(en, m);
+    for (c_int j = 0; j < n; j++) dn[j] = (c_float)1.0 / sqrt(dn[j]);
+    for (c_int i = 0; i < m; i++) en[i] = (c_float)1.0 / sqrt(en[i]);
+    /* P <- D P D (row factor first, then column factor), A <- E A D, q <- D q */
+    for (c_int j = 0; j < n; j++)
+      for (c_int k = P->p[j]; k < P->p[j + 1]; k++) { P->x[k] *= dn[P->i[k]]; }
+    for (c_int j = 0; j < n; j++)
+      for (c_int k = P->p[j]; k < P->p[j + 1]; k++) { P->x[k] *= dn[j]; }
+    for (c_int j = 0; j < n; j++)
+      for (c_int k = A->p[j]; k < A->p[j + 1]; k++) { A->x[k] *= en[A->i[k]]; }
+    for (c_int j = 0; j < n; j++)
+      for (c_int k = A->p[j]; k < A->p[j + 1]; k++) { A->x[k] *= dn[j]; }
+    for (c_int j = 0; j < n; j++) { q[j] = q[j] * dn[j]; D[j] = dn[j] * D[j]; }
+    for (c_int i = 0; i < m; i++) E[i] = en[i] * E[i];
+    /* cost normalisation */
+    sym_col_norms(P, dn);
+    c_float mean = 0.0;
+    for (c_int j = 0; j < n; j++) mean += dn[j];
+    mean /= (c_float)n;
+    c_float qn = absmax(q, n);
+    clip_scale(&qn, 1);
+    c_float ct = HMAX(mean, qn);
+    clip_scale(&ct, 1);
+    ct = 1. / ct;
+    for (c_int k = 0; k < P->p[n]; k++) P->x[k] *= ct;
+    for (c_int j = 0; j < n; j++) q[j] *= ct;
+    w->scaling->c *= ct;
+  }
+  w->scaling->cinv = 1. / w->scaling->c;
+  for (c_int j = 0; j < n; j++) w->scaling->Dinv[j] = (c_float)1.0 / D[j];
+  for (c_int i = 0; i < m; i++) w->scaling->Einv[i] = (c_float)1.0 / E[i];
+  for (c_int i = 0; i < m; i++) { w->data->l[i] = w->data->l[i] * E[i]; w->data->u[i] = w->data->u[i] * E[i]; }
+}
+
+static void unequilibrate(OSQPWorkspace *w) {   /* src/scaling.c:160-175 */
+  c_int n = w->data->n, m = w->data->m;
+  csc *P = w->data->P, *A = w->data->A;
+  const OSQPScaling *s = w->scaling;
+  for (c_int k = 0; k < P->p[n]; k++) P->x[k] *= s->cinv;
+  for (c_int j = 0; j < n; j++)
+    for (c_int k = P->p[j]; k < P->p[j + 1]; k++) P->x[k] *= s->Dinv[P->i[k]];
+  for (c_int j = 0; j < n; j++)
+    for (c_int k = P->p[j]; k < P->p[j + 1]; k++) P->x[k] *= s->Dinv[j];
+  for (c_int j = 0; j < n; j++) { w->data->q[j] *= s->cinv; w->data->q[j] = w->data->q[j] * s->Dinv[j]; }
+  for (c_int j = 0; j < n; j++)
+    for (c_int k = A->p[j]; k < A->p[j + 1]; k++) A->x[k] *= s->Einv[A->i[k]];
+  for (c_int j = 0; j < n; j++)
+    for (c_int k = A->p[j]; k < A->p[j + 1]; k++) A->x[k] *= s->Dinv[j];
+  for (c_int i = 0; i < m; i++) { w->data->l[i] = w->data->l[i] * s->Einv[i]; w->data->u[i] = w->data->u[i] * s->Einv[i]; }
+}
+
+/* ------------------------------------------------------------------------ */
+/* rho by constraint class (src/auxil.c:76-142)                               */
+/* ------------------------------------------------------------------------ */
+static c_int row_class(c_float l, c_float u) {
+  if (l < -BOUND_INF && u > BOUND_INF) return -1;
+  if (u - l < RHO_TOL) return 1;
+  return 0;
+}
+static c_float rho_of_class(c_int cls, c_float rho) {
+  return cls == -1 ? RHO_MIN : (cls == 1 ? RHO_EQ_OVER_RHO_INEQ * rho : rho);
+}
+
+static void init_rho_vec(OSQPWorkspace *w) {
+  w->settings->rho = HMIN(HMAX(w->settings->rho, RHO_MIN), RHO_MAX);
+  for (c_int i = 0; i < w->data->m; i++) {
+    w->constr_type[i] = row_class(w->data->l[i], w->data->u[i]);
+    w->rho_vec[i] = rho_of_class(w->constr_type[i], w->settings->rho);
+    w->rho_inv_vec[i] = 1. / w->rho_vec[i];
+  }
+}
+
+static c_int reclassify_rows(OSQPWorkspace *w) {
+  c_int changed = 0;
+  for (c_int i = 0; i < w->data->m; i++) {
+    c_int cls = row_class(w->data->l[i], w->data->u[i]);
+    if (cls == w->constr_type[i]) continue;
+    w->constr_type[i] = cls;
+    w->rho_vec[i] = rho_of_class(cls, w->settings->rho);
+    w->rho_inv_vec[i] = 1. / w->rho_vec[i];
+    changed = 1;
+  }
+  if (changed) return w->linsys_solver->update_rho_vec(w->linsys_solver, w->rho_vec);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* setup / cleanup                                                            */
+/* ------------------------------------------------------------------------ */
+static c_int setup_fail(c_int code, const char *msg) {
+  fprintf(stderr, "ERROR in osqp_setup: %s\n", msg);
+  return code;
+}
+
+void cold_start(OSQPWorkspace *w) {   /* src/auxil.c:155-159 */
+  memset(w->x, 0, (size_t)w->data->n * sizeof(c_float));
+  if (w->data->m) {
+    memset(w->z, 0, (size_t)w->data->m * sizeof(c_float));
+    memset(w->y, 0, (size_t)w->data->m * sizeof(c_float));
+  }
+  if (w->linsys_solver && PCG(w)->eng) hipeng_cold_start(PCG(w)->eng);
+}
+
+c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings) {
+  if (check_data(data)) return setup_fail(OSQP_DATA_VALIDATION_ERROR, "Data validation returned failure");
+  if (check_settings(settings)) return setup_fail(OSQP_SETTINGS_VALIDATION_ERROR, "Settings validation returned failure");
+  OSQPWorkspace *w = (OSQPWorkspace *)calloc(1, sizeof(OSQPWorkspace));
+  if (!w) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
+  *workp = w;   /* set early: cleanup after a failed setup must work (osqp.c:88-90) */
+  const c_int n = data->n, m = data->m;
+  w->timer = (OSQPTimer *)malloc(sizeof(OSQPTimer));
+  if (!w->timer) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
+  tic(w->timer);
+
+  w->data = (OSQPData *)calloc(1, sizeof(OSQPData));
+  if (!w->data) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
+  w->data->n = n; w->data->m = m;
+  w->data->P = dup_csc(data->P); w->data->A = dup_csc(data->A);
+  w->data->q = dup_vec(data->q, n); w->data->l = dup_vec(data->l, m); w->data->u = dup_vec(data->u, m);
+  w->rho_vec = zero_vec(m); w->rho_inv_vec = zero_vec(m);
+  w->constr_type = (c_int *)calloc((size_t)(m > 0 ? m : 1), sizeof(c_int));
+  w->x = zero_vec(n); w->z = zero_vec(m); w->xz_tilde = zero_vec(n + m);
+  w->x_prev = zero_vec(n); w->z_prev = zero_vec(m); w->y = zero_vec(m);
+  w->Ax = zero_vec(m); w->Px = zero_vec(n); w->Aty = zero_vec(n);
+  w->delta_y = zero_vec(m); w->Atdelta_y = zero_vec(n);
+  w->delta_x = zero_vec(n); w->Pdelta_x = zero_vec(n); w->Adelta_x = zero_vec(m);
+  w->settings = (OSQPSettings *)malloc(sizeof(OSQPSettings));
+  w->solution = (OSQPSolution *)calloc(1, sizeof(OSQPSolution));
+  w->info = (OSQPInfo *)calloc(1, sizeof(OSQPInfo));
+  w->pol = (OSQPPolish *)calloc(1, sizeof(OSQPPolish));
+  if (!w->data->P || !w->data->A || !w->data->q || !w->data->l || !w->data->u || !w->rho_vec ||
+      !w->rho_inv_vec || !w->constr_type || !w->x || !w->z || !w->xz_tilde || !w->x_prev ||
+      !w->z_prev || !w->y || !w->Ax || !w->Px || !w->Aty || !w->delta_y || !w->Atdelta_y ||
+      !w->delta_x || !w->Pdelta_x || !w->Adelta_x || !w->settings || !w->solution || !w->info || !w->pol)
+    return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
+  *w->settings = *settings;
+  w->solution->x = zero_vec(n); w->solution->y = zero_vec(m);
+  size_t mm = (size_t)(m > 0 ? m : 1);
+  w->pol->Alow_to_A = (c_int *)malloc(mm * sizeof(c_int)); w->pol->Aupp_to_A = (c_int *)malloc(mm * sizeof(c_int));
+  w->pol->A_to_Alow = (c_int *)malloc(mm * sizeof(c_int)); w->pol->A_to_Aupp = (c_int *)malloc(mm * sizeof(c_int));
+  w->pol->x = zero_vec(n); w->pol->z = zero_vec(m); w->pol->y = zero_vec(m);
+  if (!w->solution->x || !w->solution->y || !w->pol->Alow_to_A || !w->pol->Aupp_to_A ||
+      !w->pol->A_to_Alow || !w->pol->A_to_Aupp || !w->pol->x || !w->pol->z || !w->pol->y)
+    return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
+
+  if (settings->scaling) {
+    w->scaling = (OSQPScaling *)calloc(1, sizeof(OSQPScaling));
+    if (!w->scaling) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
+    w->scaling->D = zero_vec(n); w->scaling->Dinv = zero_vec(n);
+    w->scaling->E = zero_vec(m); w->scaling->Einv = zero_vec(m);
+    w->D_temp = zero_vec(n); w->D_temp_A = zero_vec(n); w->E_temp = zero_vec(m);
+    if (!w->scaling->D || !w->scaling->Dinv || !w->scaling->E || !w->scaling->Einv ||
+        !w->D_temp || !w->D_temp_A || !w->E_temp)
+      return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
+    equilibrate(w);
+  }
+  init_rho_vec(w);
+
+  /* device engine = the workspace's linear-system plugin */
+  hip_pcg_solver *s = pcg_alloc(n, m, w->settings->sigma, 0);
+  if (!s) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
+  s->owner = w;
+  w->linsys_solver = (LinSysSolver *)s;
+  hipeng_params prm;
+  fill_params(&prm, w->settings->sigma, w->settings->alpha, n);
+  opt_init();
+  int rc = hipeng_create(&s->eng, w->data->P, w->data->A, w->data->q, w->data->l, w->data->u,
+                         w->rho_vec, &prm, (int)g_opt.device);
+  if (rc == HIPENG_ERR_NO_DEVICE)
+    return setup_fail(OSQP_LINSYS_SOLVER_LOAD_ERROR, "no HIP device: the HIP PCG solver cannot be loaded");
+  if (rc) return setup_fail(OSQP_LINSYS_SOLVER_INIT_ERROR, "HIP engine initialisation failed");
+  if (w->scaling) hipeng_set_scaling(s->eng, w->scaling->D, w->scaling->E, w->scaling->c);
+
+  w->info->status_polish = 0;
+  put_status(w->info, OSQP_UNSOLVED);
+  w->info->setup_time = toc(w->timer);
+  w->first_run = 1; w->clear_update_time = 0; w->rho_update_from_solve = 0;
+  w->info->rho_updates = 0;
+  w->info->rho_estimate = w->settings->rho;
+  w->summary_printed = 0;
+  if (w->settings->verbose)
+    printf("osqp_amd (HIP/gfx950): variables n = %lld, constraints m = %lld, nnz(P)+nnz(A) = %lld; "
+           "linear system solver = hip pcg\n", (long long)n, (long long)m,
+           (long long)(w->data->P->p[n] + w->data->A->p[n]));
+  return 0;
+}
+
+c_int osqp_cleanup(OSQPWorkspace *w) {   /* src/osqp.c:659-757 */
+  if (!w) return 0;
+  if (w->data) {
+    free_csc(w->data->P); free_csc(w->data->A);
+    free(w->data->q); free(w->data->l); free(w->data->u); free(w->data);
+  }
+  if (w->scaling) {
+    free(w->scaling->D); free(w->scaling->Dinv); free(w->scaling->E); free(w->scaling->Einv);
+    free(w->scaling);
+  }
+  free(w->D_temp); free(w->D_temp_A); free(w->E_temp);
+  if (w->linsys_solver && w->linsys_solver->free) w->linsys_solver->free(w->linsys_solver);
+  if (w->pol) {
+    free(w->pol->Alow_to_A); free(w->pol->Aupp_to_A); free(w->pol->A_to_Alow); free(w->pol->A_to_Aupp);
+    free(w->pol->x); free(w->pol->z); free(w->pol->y); free(w->pol);
+  }
+  free(w->rho_vec); free(w->rho_inv_vec); free(w->constr_type);
+  free(w->x); free(w->z); free(w->xz_tilde); free(w->x_prev); free(w->z_prev); free(w->y);
+  free(w->Ax); free(w->Px); free(w->Aty); free(w->delta_y); free(w->Atdelta_y);
+  free(w->delta_x); free(w->Pdelta_x); free(w->Adelta_x);
+  free(w->settings);
+  if (w->solution) { free(w->solution->x); free(w->solution->y); free(w->solution); }
+  free(w->info); free(w->timer); free(w);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* info from device scalars (src/auxil.c:227-359, 564-629)                    */
+/* ------------------------------------------------------------------------ */
+static c_int use_unscaled(const OSQPWorkspace *w) {
+  return w->settings->scaling && !w->settings->scaled_termination;
+}
+
+static c_int refresh_info(OSQPWorkspace *w, c_int iter, c_int with_obj) {
+  hip_pcg_solver *s = PCG(w);
+  if (hipeng_residuals(s->eng, &s->sc)) return 1;
+  s->host_syncs++;
+  s->sc_iter = iter;
+  w->info->iter = iter;
+  if (with_obj) w->info->obj_val = s->sc.obj_scaled * (w->settings->scaling ? w->scaling->cinv : 1.0);
+  if (w->data->m == 0) w->info->pri_res = 0.;
+  else w->info->pri_res = use_unscaled(w) ? s->sc.pri_res_u : s->sc.pri_res_s;
+  w->info->dua_res = use_unscaled(w) ? w->scaling->cinv * s->sc.dua_res_u : s->sc.dua_res_s;
+  w->info->solve_time = toc(w->timer);
+  w->summary_printed = 0;
+  return 0;
+}
+
+/* status decision on the reduced scalars (src/auxil.c:681-786) */
+static c_int decide_termination(OSQPWorkspace *w, c_int approximate) {
+  hip_pcg_solver *s = PCG(w);
+  hipeng_scalars *sc = &s->sc;
+  const OSQPSettings *st = w->settings;
+  const c_int un = use_unscaled(w);
+  c_float eps_abs = st->eps_abs, eps_rel = st->eps_rel;
+  c_float eps_pinf = st->eps_prim_inf, eps_dinf = st->eps_dual_inf;
+  c_int prim_ok = 0, dual_ok = 0, pinf = 0, dinf = 0;
+
+  if (w->info->pri_res > OSQP_INFTY || w->info->dua_res > OSQP_INFTY) {
+    put_status(w->info, OSQP_NON_CVX);
+    w->info->obj_val = OSQP_NAN;
+    return 1;
+  }
+  if (approximate) { eps_abs *= 10; eps_rel *= 10; eps_pinf *= 10; eps_dinf *= 10; }
+
+  /* candidates for the second-stage (SpMV) certificates */
+  c_int need_cert = 0, pinf_cand = 0, dinf_cand = 0;
+  c_float ndy = un ? sc->dy_norm_u : sc->dy_norm_s;
+  c_float ndx = un ? sc->dx_norm_u : sc->dx_norm_s;
+  c_float cs = un ? w->scaling->c : 1.0;
+
+  if (w->data->m == 0) prim_ok = 1;
+  else {
+    c_float eps_prim = eps_abs + eps_rel * (un ? HMAX(sc->z_u, sc->Ax_u) : HMAX(sc->z_s, sc->Ax_s));
+    if (w->info->pri_res < eps_prim) prim_ok = 1;
+    else if (ndy > OSQP_DIVISION_TOL && sc->dy_lhs < eps_pinf * ndy) { pinf_cand = 1; need_cert = 1; }
+  }
+  {
+    c_float nrm = un ? w->scaling->cinv * HMAX(HMAX(sc->q_u, sc->Aty_u), sc->Px_u)
+                     : HMAX(HMAX(sc->q_s, sc->Aty_s), sc->Px_s);
+    c_float eps_dual = eps_abs + eps_rel * nrm;
+    if (w->info->dua_res < eps_dual) dual_ok = 1;
+    else if (ndx > OSQP_DIVISION_TOL && sc->q_dx < cs * eps_dinf * ndx) { dinf_cand = 1; need_cert = 1; }
+  }
+  if (need_cert && !(prim_ok && dual_ok)) {
+    if (hipeng_certificates(s->eng, eps_dinf * ndx, (int)un, sc)) return 0;
+    s->host_syncs++;
+    if (pinf_cand) pinf = (un ? sc->Atdy_u : sc->Atdy_s) < eps_pinf * ndy;
+    if (dinf_cand) dinf = ((un ? sc->Pdx_u : sc->Pdx_s) < cs * eps_dinf * ndx) && (sc->Adx_viol == 0.0);
+  }
+
+  if (prim_ok && dual_ok) {
+    put_status(w->info, approximate ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED);
+    return 1;
+  }
+  if (pinf) {
+    put_status(w->info, approximate ? OSQP_PRIMAL_INFEASIBLE_INACCURATE : OSQP_PRIMAL_INFEASIBLE);
+    w->info->obj_val = OSQP_INFTY;
+    return 1;
+  }
+  if (dinf) {
+    put_status(w->info, approximate ? OSQP_DUAL_INFEASIBLE_INACCURATE : OSQP_DUAL_INFEASIBLE);
+    w->info->obj_val = -OSQP_INFTY;
+    return 1;
+  }
+  return 0;
+}
+
+/* src/auxil.c:13-52 on the scaled norms */
+static c_float estimate_rho(const OSQPWorkspace *w) {
+  const hipeng_scalars *sc = &PCG(w)->sc;
+  c_float pri = (w->data->m ? sc->pri_res_s : 0.0) / (HMAX(sc->z_s, sc->Ax_s) + OSQP_DIVISION_TOL);
+  c_float dua = sc->dua_res_s / (HMAX(HMAX(sc->q_s, sc->Aty_s), sc->Px_s) + OSQP_DIVISION_TOL);
+  c_float r = w->settings->rho * sqrt(pri / dua);
+  return HMIN(HMAX(r, RHO_MIN), RHO_MAX);
+}
+
+static c_int maybe_adapt_rho(OSQPWorkspace *w) {   /* src/auxil.c:54-74 */
+  c_float r = estimate_rho(w);
+  c_int rc = 0;
+  w->info->rho_estimate = r;
+  if (r > w->settings->rho * w->settings->adaptive_rho_tolerance ||
+      r < w->settings->rho / w->settings->adaptive_rho_tolerance) {
+    rc = osqp_update_rho(w, r);
+    w->info->rho_updates += 1;
+  }
+  return rc;
+}
+
+static void print_line(const OSQPWorkspace *w) {
+  printf("%4lld  %12.4e  %9.2e  %9.2e  %9.2e  %9.2es\n", (long long)w->info->iter, w->info->obj_val,
+         w->info->pri_res, w->info->dua_res, w->settings->rho,
+         w->info->solve_time + (w->first_run ? w->info->setup_time : w->info->update_time));
+}
+
+/* src/auxil.c:524-562 + src/scaling.c:177-192 */
+static c_int extract_solution(OSQPWorkspace *w) {
+  hip_pcg_solver *s = PCG(w);
+  const c_int n = w->data->n, m = w->data->m;
+  const c_int v = w->info->status_val;
+  const c_int pinf = (v == OSQP_PRIMAL_INFEASIBLE || v == OSQP_PRIMAL_INFEASIBLE_INACCURATE);
+  if (hipeng_download(s->eng, w->x, w->y, w->z, w->delta_x, w->delta_y, (int)pinf)) return 1;
+  s->host_syncs++;
+  if (solution_exists(w->info)) {
+    memcpy(w->solution->x, w->x, (size_t)n * sizeof(c_float));
+    if (m) memcpy(w->solution->y, w->y, (size_t)m * sizeof(c_float));
+    if (w->settings->scaling) {
+      for (c_int j = 0; j < n; j++) w->solution->x[j] = w->solution->x[j] * w->scaling->D[j];
+      for (c_int i = 0; i < m; i++) w->solution->y[i] = w->solution->y[i] * w->scaling->E[i];
+      for (c_int i = 0; i < m; i++) w->solution->y[i] *= w->scaling->cinv;
+    }
+  } else {
+    for (c_int j = 0; j < n; j++) w->solution->x[j] = OSQP_NAN;
+    for (c_int i = 0; i < m; i++) w->solution->y[i] = OSQP_NAN;
+    if (pinf) {   /* certificate: E.dy (auxil.c:757-760), normalised (auxil.c:545-549) */
+      if (use_unscaled(w)) for (c_int i = 0; i < m; i++) w->delta_y[i] = w->delta_y[i] * w->scaling->E[i];
+      c_float nv = absmax(w->delta_y, m);
+      for (c_int i = 0; i < m; i++) w->delta_y[i] *= 1. / nv;
+    }
+    if (v == OSQP_DUAL_INFEASIBLE || v == OSQP_DUAL_INFEASIBLE_INACCURATE) {
+      if (use_unscaled(w)) for (c_int j = 0; j < n; j++) w->delta_x[j] = w->delta_x[j] * w->scaling->D[j];
+      c_float nv = absmax(w->delta_x, n);
+      for (c_int j = 0; j < n; j++) w->delta_x[j] *= 1. / nv;
+    }
+    cold_start(w);
+  }
+  return 0;
+}
+
+static c_int run_polish(OSQPWorkspace *w);
+
+/* ------------------------------------------------------------------------ */
+/* osqp_solve (src/osqp.c:288-654)                                            */
+/* ------------------------------------------------------------------------ */
+c_int osqp_solve(OSQPWorkspace *w) {
+  if (!w) { fprintf(stderr, "ERROR in osqp_solve: Workspace not initialized\n"); return OSQP_WORKSPACE_NOT_INIT_ERROR; }
+  hip_pcg_solver *s = PCG(w);
+  OSQPSettings *st = w->settings;
+  c_int exitflag = 0, iter = 0, can_check = 0, can_print = 0;
+  const c_int with_obj = st->verbose;
+
+  if (w->clear_update_time == 1) w->info->update_time = 0.0;
+  w->rho_update_from_solve = 1;
+  tic(w->timer);
+  if (st->verbose) printf("iter   objective    pri res    dua res    rho        time\n");
+
+  hipeng_params prm;
+  fill_params(&prm, st->sigma, st->alpha, w->data->n);
+  if (hipeng_set_params(s->eng, &prm)) { exitflag = 1; goto done; }
+
+  c_int rho_interval = st->adaptive_rho_interval;
+  if (st->adaptive_rho && !rho_interval)
+    rho_interval = st->check_termination ? ADAPTIVE_RHO_MULTIPLE_TERMINATION * st->check_termination
+                                         : ADAPTIVE_RHO_FIXED;
+
+  if (!st->warm_start) cold_start(w);
+  s->sc_iter = -1;
+
+  while (iter < st->max_iter) {
+    /* next iteration count at which the reference would look at the iterates */
+    c_int next = st->max_iter;
+    if (st->check_termination) next = HMIN(next, (iter / st->check_termination + 1) * st->check_termination);
+    if (st->adaptive_rho && rho_interval) next = HMIN(next, (iter / rho_interval + 1) * rho_interval);
+    if (st->verbose) next = HMIN(next, iter == 0 ? 1 : (iter / PRINT_INTERVAL + 1) * PRINT_INTERVAL);
+    next = HMIN(next, iter + (st->time_limit ? 8 : 128));
+    if (hipeng_run_admm(s->eng, next - iter)) { exitflag = 1; goto done; }
+    s->host_syncs++;
+    iter = next;
+
+    if (st->time_limit) {
+      c_float t = (w->first_run ? w->info->setup_time : w->info->update_time) + toc(w->timer);
+      if (t >= st->time_limit) {
+        put_status(w->info, OSQP_TIME_LIMIT_REACHED);
+        if (st->verbose) printf("run time limit reached\n");
+        can_print = 0; can_check = 0;
+        break;
+      }
+    }
+    can_check = st->check_termination && (iter % st->check_termination == 0);
+    can_print = st->verbose && ((iter % PRINT_INTERVAL == 0) || (iter == 1));
+    if (can_check || can_print) {
+      if (refresh_info(w, iter, with_obj)) { exitflag = 1; goto done; }
+      if (can_print) { print_line(w); w->summary_printed = 1; }
+      if (can_check && decide_termination(w, 0)) break;
+    }
+    if (st->adaptive_rho && rho_interval && (iter % rho_interval == 0)) {
+      if (!can_check && !can_print && refresh_info(w, iter, with_obj)) { exitflag = 1; goto done; }
+      if (maybe_adapt_rho(w)) { fprintf(stderr, "ERROR in osqp_solve: Failed rho update\n"); exitflag = 1; goto done; }
+    }
+  }
+
+  if (!can_check) {
+    if (!can_print && refresh_info(w, iter, with_obj)) { exitflag = 1; goto done; }
+    if (st->verbose && !w->summary_printed) { print_line(w); w->summary_printed = 1; }
+    decide_termination(w, 0);
+  }
+  if (!with_obj && solution_exists(w->info)) {
+    if (s->sc_iter != iter && refresh_info(w, iter, 0)) { exitflag = 1; goto done; }
+    w->info->obj_val = s->sc.obj_scaled * (st->scaling ? w->scaling->cinv : 1.0);
+  }
+  if (st->verbose && !w->summary_printed) { print_line(w); w->summary_printed = 1; }
+
+  if (w->info->status_val == OSQP_UNSOLVED) {
+    if (!decide_termination(w, 1)) put_status(w->info, OSQP_MAX_ITER_REACHED);
+  }
+  if (w->info->status_val == OSQP_TIME_LIMIT_REACHED) {
+    if (!decide_termination(w, 1)) put_status(w->info, OSQP_TIME_LIMIT_REACHED);
+  }
+  w->info->rho_estimate = estimate_rho(w);
+  w->info->solve_time = toc(w->timer);
+
+  /* host mirrors of the iterates + solution (one download per solve) */
+  if (extract_solution(w)) { exitflag = 1; goto done; }
+
+  if (st->polish && w->info->status_val == OSQP_SOLVED) run_polish(w);
+
+  w->info->run_time = (w->first_run ? w->info->setup_time : w->info->update_time) +
+                      w->info->solve_time + w->info->polish_time;
+  if (w->first_run) w->first_run = 0;
+  w->clear_update_time = 1;
+  w->rho_update_from_solve = 0;
+  if (st->verbose)
+    printf("status: %s, iterations: %lld, objective: %.4f, run time: %.2es, rho estimate: %.2e\n",
+           w->info->status, (long long)w->info->iter, w->info->obj_val, w->info->run_time,
+           w->info->rho_estimate);
+done:
+  return exitflag;
+}
+
+/* ------------------------------------------------------------------------ */
+/* data updates (src/osqp.c:765-1332)                                         */
+/* ------------------------------------------------------------------------ */
+static void upd_begin(OSQPWorkspace *w) {
+  if (w->clear_update_time == 1) { w->clear_update_time = 0; w->info->update_time = 0.0; }
+  tic(w->timer);
+}
+static void upd_end(OSQPWorkspace *w) { w->info->update_time += toc(w->timer); }
+#define NEED_WORK(w) do { if (!(w)) { fprintf(stderr, "ERROR in %s: Workspace not initialized\n", __func__); \
+                                      return OSQP_WORKSPACE_NOT_INIT_ERROR; } } while (0)
+
+c_int osqp_update_lin_cost(OSQPWorkspace *w, const c_float *q_new) {
+  NEED_WORK(w);
+  upd_begin(w);
+  const c_int n = w->data->n;
+  memcpy(w->data->q, q_new, (size_t)n * sizeof(c_float));
+  if (w->settings->scaling) {
+    for (c_int j = 0; j < n; j++) w->data->q[j] = w->data->q[j] * w->scaling->D[j];
+    for (c_int j = 0; j < n; j++) w->data->q[j] *= w->scaling->c;
+  }
+  if (hipeng_upload_q(PCG(w)->eng, w->data->q)) return 1;
+  info_reset(w->info);
+  upd_end(w);
+  return 0;
+}
+
+static c_int push_bounds(OSQPWorkspace *w) {
+  if (hipeng_upload_bounds(PCG(w)->eng, w->data->l, w->data->u)) return 1;
+  info_reset(w->info);
+  return reclassify_rows(w);
+}
+
+c_int osqp_update_bounds(OSQPWorkspace *w, const c_float *l_new, const c_float *u_new) {
+  NEED_WORK(w);
+  upd_begin(w);
+  const c_int m = w->data->m;
+  for (c_int i = 0; i < m; i++)
+    if (l_new[i] > u_new[i]) { fprintf(stderr, "ERROR in osqp_update_bounds: lower bound must be lower than or equal to upper bound\n"); return 1; }
+  memcpy(w->data->l, l_new, (size_t)m * sizeof(c_float));
+  memcpy(w->data->u, u_new, (size_t)m * sizeof(c_float));
+  if (w->settings->scaling)
+    for (c_int i = 0; i < m; i++) { w->data->l[i] = w->data->l[i] * w->scaling->E[i]; w->data->u[i] = w->data->u[i] * w->scaling->E[i]; }
+  c_int rc = push_bounds(w);
+  upd_end(w);
+  return rc;
+}
+
+c_int osqp_update_lower_bound(OSQPWorkspace *w, const c_float *l_new) {
+  NEED_WORK(w);
+  upd_begin(w);
+  const c_int m = w->data->m;
+  memcpy(w->data->l, l_new, (size_t)m * sizeof(c_float));
+  if (w->settings->scaling) for (c_int i = 0; i < m; i++) w->data->l[i] = w->data->l[i] * w->scaling->E[i];
+  for (c_int i = 0; i < m; i++)
+    if (w->data->l[i] > w->data->u[i]) { fprintf(stderr, "ERROR in osqp_update_lower_bound: upper bound must be greater than or equal to lower bound\n"); return 1; }
+  c_int rc = push_bounds(w);
+  upd_end(w);
+  return rc;
+}
+
+c_int osqp_update_upper_bound(OSQPWorkspace *w, const c_float *u_new) {
+  NEED_WORK(w);
+  upd_begin(w);
+  const c_int m = w->data->m;
+  memcpy(w->data->u, u_new, (size_t)m * sizeof(c_float));
+  if (w->settings->scaling) for (c_int i = 0; i < m; i++) w->data->u[i] = w->data->u[i] * w->scaling->E[i];
+  for (c_int i = 0; i < m; i++)
+    if (w->data->u[i] < w->data->l[i]) { fprintf(stderr, "ERROR in osqp_update_upper_bound: lower bound must be lower than or equal to upper bound\n"); return 1; }
+  c_int rc = push_bounds(w);
+  upd_end(w);
+  return rc;
+}
+
+static c_int warm(OSQPWorkspace *w, const c_float *x, const c_float *y) {
+  const c_int n = w->data->n, m = w->data->m;
+  if (!w->settings->warm_start) w->settings->warm_start = 1;
+  if (x) {
+    memcpy(w->x, x, (size_t)n * sizeof(c_float));
+    if (w->settings->scaling) for (c_int j = 0; j < n; j++) w->x[j] = w->x[j] * w->scaling->Dinv[j];
+  }
+  if (y) {
+    memcpy(w->y, y, (size_t)m * sizeof(c_float));
+    if (w->settings->scaling) {
+      for (c_int i = 0; i < m; i++) w->y[i] = w->y[i] * w->scaling->Einv[i];
+      for (c_int i = 0; i < m; i++) w->y[i] *= w->scaling->c;
+    }
+  }
+  /* z = A x is evaluated on the device (osqp.c:960-963) */
+  return hipeng_set_iterates(PCG(w)->eng, x ? w->x : NULL, y ? w->y : NULL) ? 1 : 0;
+}
+c_int osqp_warm_start(OSQPWorkspace *w, const c_float *x, const c_float *y) { NEED_WORK(w); return warm(w, x, y); }
+c_int osqp_warm_start_x(OSQPWorkspace *w, const c_float *x) { NEED_WORK(w); return warm(w, x, NULL); }
+c_int osqp_warm_start_y(OSQPWorkspace *w, const c_float *y) { NEED_WORK(w); return warm(w, NULL, y); }
+
+static c_int patch(OSQPWorkspace *w, const c_float *Px, const c_int *Pi, c_int Pn, int doP,
+                   const c_float *Ax, const c_int *Ai, c_int An, int doA) {
+  const c_int nnzP = w->data->P->p[w->data->P->n], nnzA = w->data->A->p[w->data->A->n];
+  upd_begin(w);
+  if (doP && Pi && Pn > nnzP) { fprintf(stderr, "ERROR: new number of elements greater than elements in P\n"); return 1; }
+  if (doA && Ai && An > nnzA) { fprintf(stderr, "ERROR: new number of elements greater than elements in A\n"); return doP ? 2 : 1; }
+  if (w->settings->scaling) unequilibrate(w);
+  if (doP) {
+    if (Pi) for (c_int k = 0; k < Pn; k++) w->data->P->x[Pi[k]] = Px[k];
+    else    for (c_int k = 0; k < nnzP; k++) w->data->P->x[k] = Px[k];
+  }
+  if (doA) {
+    if (Ai) for (c_int k = 0; k < An; k++) w->data->A->x[Ai[k]] = Ax[k];
+    else    for (c_int k = 0; k < nnzA; k++) w->data->A->x[k] = Ax[k];
+  }
+  hipeng *e = PCG(w)->eng;
+  if (w->settings->scaling) {
+    equilibrate(w);   /* also rescales q, l, u: all of them go back to the device */
+    if (hipeng_set_scaling(e, w->scaling->D, w->scaling->E, w->scaling->c) ||
+        hipeng_upload_q(e, w->data->q) || hipeng_upload_bounds(e, w->data->l, w->data->u)) return 1;
+  }
+  c_int rc = w->linsys_solver->update_matrices(w->linsys_solver, w->data->P, w->data->A);
+  info_reset(w->info);
+  upd_end(w);
+  return rc;
+}
+
+c_int osqp_update_P(OSQPWorkspace *w, const c_float *Px, const c_int *Pi, c_int Pn) {
+  NEED_WORK(w); return patch(w, Px, Pi, Pn, 1, NULL, NULL, 0, 0);
+}
+c_int osqp_update_A(OSQPWorkspace *w, const c_float *Ax, const c_int *Ai, c_int An) {
+  NEED_WORK(w); return patch(w, NULL, NULL, 0, 0, Ax, Ai, An, 1);
+}
+c_int osqp_update_P_A(OSQPWorkspace *w, const c_float *Px, const c_int *Pi, c_int Pn,
+                      const c_float *Ax, const c_int *Ai, c_int An) {
+  NEED_WORK(w); return patch(w, Px, Pi, Pn, 1, Ax, Ai, An, 1);
+}
+
+c_int osqp_update_rho(OSQPWorkspace *w, c_float rho_new) {   /* src/osqp.c:1281-1332 */
+  NEED_WORK(w);
+  if (rho_new <= 0) { fprintf(stderr, "ERROR in osqp_update_rho: rho must be positive\n"); return 1; }
+  double t0 = 0;
+  if (!w->rho_update_from_solve) {
+    if (w->clear_update_time == 1) { w->clear_update_time = 0; w->info->update_time = 0.0; }
+    t0 = now_s();
+  }
+  w->settings->rho = HMIN(HMAX(rho_new, RHO_MIN), RHO_MAX);
+  for (c_int i = 0; i < w->data->m; i++) {
+    if (w->constr_type[i] == 0) { w->rho_vec[i] = w->settings->rho; w->rho_inv_vec[i] = 1. / w->settings->rho; }
+    else if (w->constr_type[i] == 1) { w->rho_vec[i] = RHO_EQ_OVER_RHO_INEQ * w->settings->rho; w->rho_inv_vec[i] = 1. / w->rho_vec[i]; }
+  }
+  c_int rc = w->linsys_solver->update_rho_vec(w->linsys_solver, w->rho_vec);
+  if (!w->rho_update_from_solve) w->info->update_time += now_s() - t0;
+  return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* settings setters (src/osqp.c:1339-1617)                                    */
+/* ------------------------------------------------------------------------ */
+#define SETTER(name, type, field, cond, msg)                               \
+  c_int name(OSQPWorkspace *w, type v) {                                   \
+    NEED_WORK(w);                                                          \
+    if (!(cond)) { fprintf(stderr, "ERROR in %s: %s\n", __func__, msg); return 1; } \
+    w->settings->field = v;                                                \
+    return 0;                                                              \
+  }
+SETTER(osqp_update_max_iter, c_int, max_iter, v > 0, "max_iter must be positive")
+SETTER(osqp_update_eps_abs, c_float, eps_abs, v >= 0., "eps_abs must be nonnegative")
+SETTER(osqp_update_eps_rel, c_float, eps_rel, v >= 0., "eps_rel must be nonnegative")
+SETTER(osqp_update_eps_prim_inf, c_float, eps_prim_inf, v >= 0., "eps_prim_inf must be nonnegative")
+SETTER(osqp_update_eps_dual_inf, c_float, eps_dual_inf, v >= 0., "eps_dual_inf must be nonnegative")
+SETTER(osqp_update_alpha, c_float, alpha, (v > 0. && v < 2.), "alpha must be between 0 and 2")
+SETTER(osqp_update_warm_start, c_int, warm_start, (v == 0 || v == 1), "warm_start should be either 0 or 1")
+SETTER(osqp_update_scaled_termination, c_int, scaled_termination, (v == 0 || v == 1), "scaled_termination should be either 0 or 1")
+SETTER(osqp_update_check_termination, c_int, check_termination, v >= 0, "check_termination should be nonnegative")
+SETTER(osqp_update_delta, c_float, delta, v > 0., "delta must be positive")
+SETTER(osqp_update_polish, c_int, polish, (v == 0 || v == 1), "polish should be either 0 or 1")
+SETTER(osqp_update_polish_refine_iter, c_int, polish_refine_iter, v >= 0, "polish_refine_iter must be nonnegative")
+SETTER(osqp_update_verbose, c_int, verbose, (v == 0 || v == 1), "verbose should be either 0 or 1")
+SETTER(osqp_update_time_limit, c_float, time_limit, v >= 0., "time_limit must be nonnegative")
+
+/* ------------------------------------------------------------------------ */
+/* polish (src/polish.c:19-350) through the plugin with polish = 1            */
+/* ------------------------------------------------------------------------ */
+static void host_spmv(const csc *A, const c_float *x, c_float *y, int sign) {        /* y += sign * A x */
+  for (c_int j = 0; j < A->n; j++)
+    for (c_int k = A->p[j]; k < A->p[j + 1]; k++) y[A->i[k]] += sign * A->x[k] * x[j];
+}
+static void host_spmv_t(const csc *A, const c_float *x, c_float *y, int sign, int skip_diag) { /* y += sign * A' x */
+  for (c_int j = 0; j < A->n; j++)
+    for (c_int k = A->p[j]; k < A->p[j + 1]; k++)
+      if (!(skip_diag && A->i[k] == j)) y[j] += sign * A->x[k] * x[A->i[k]];
+}
+
+static c_int run_polish(OSQPWorkspace *w) {
+  OSQPPolish *p = w->pol;
+  hip_pcg_solver *s = PCG(w);
+  const c_int n = w->data->n, m = w->data->m;
+  const csc *A = w->data->A;
+  tic(w->timer);
+  /* active-set guess from the ADMM (z, y) (polish.c:19-103) */
+  p->n_low = p->n_upp = 0;
+  for (c_int i = 0; i < m; i++) {
+    if (w->z[i] - w->data->l[i] < -w->y[i]) { p->Alow_to_A[p->n_low] = i; p->A_to_Alow[i] = p->n_low++; }
+    else p->A_to_Alow[i] = -1;
+  }
+  for (c_int i = 0; i < m; i++) {
+    if (w->data->u[i] - w->z[i] < w->y[i]) { p->Aupp_to_A[p->n_upp] = i; p->A_to_Aupp[i] = p->n_upp++; }
+    else p->A_to_Aupp[i] = -1;
+  }
+  const c_int mred = p->n_low + p->n_upp;
+  c_int cnt = 0;
+  for (c_int k = 0; k < A->p[n]; k++)
+    if (p->A_to_Alow[A->i[k]] != -1 || p->A_to_Aupp[A->i[k]] != -1) cnt++;
+  csc *Ar = (csc *)calloc(1, sizeof(csc));
+  if (!Ar) { w->info->status_polish = -1; return -1; }
+  Ar->m = mred; Ar->n = n; Ar->nz = -1; Ar->nzmax = cnt > 0 ? cnt : 1;
+  Ar->p = (c_int *)calloc((size_t)n + 1, sizeof(c_int));
+  Ar->i = (c_int *)calloc((size_t)Ar->nzmax, sizeof(c_int));
+  Ar->x = (c_float *)calloc((size_t)Ar->nzmax, sizeof(c_float));
+  cnt = 0;
+  for (c_int j = 0; j < n; j++) {
+    Ar->p[j] = cnt;
+    for (c_int k = A->p[j]; k < A->p[j + 1]; k++) {
+      c_int r = A->i[k];
+      if (p->A_to_Alow[r] != -1)      { Ar->i[cnt] = p->A_to_Alow[r];            Ar->x[cnt++] = A->x[k]; }
+      else if (p->A_to_Aupp[r] != -1) { Ar->i[cnt] = p->A_to_Aupp[r] + p->n_low; Ar->x[cnt++] = A->x[k]; }
+    }
+  }
+  Ar->p[n] = cnt;
+  p->Ared = Ar;
+
+  LinSysSolver *ls = NULL;
+  if (init_linsys_solver(&ls, w->data->P, Ar, w->settings->delta, NULL, w->settings->linsys_solver, 1)) {
+    w->info->status_polish = -1; free_csc(Ar); p->Ared = NULL; return 1;
+  }
+  const c_int N = n + mred;
+  c_float *rhs = zero_vec(N), *sol = zero_vec(N), *res = zero_vec(N);
+  for (c_int j = 0; j < n; j++) rhs[j] = -w->data->q[j];
+  for (c_int k = 0; k < p->n_low; k++) rhs[n + k] = w->data->l[p->Alow_to_A[k]];
+  for (c_int k = 0; k < p->n_upp; k++) rhs[n + p->n_low + k] = w->data->u[p->Aupp_to_A[k]];
+  memcpy(sol, rhs, (size_t)N * sizeof(c_float));
+  c_int bad = ls->solve(ls, sol);
+  for (c_int it = 0; !bad && it < w->settings->polish_refine_iter; it++) {   /* polish.c:134-181 */
+    memcpy(res, rhs, (size_t)N * sizeof(c_float));
+    host_spmv(w->data->P, sol, res, -1);
+    host_spmv_t(w->data->P, sol, res, -1, 1);
+    host_spmv_t(Ar, sol + n, res, -1, 0);
+    host_spmv(Ar, sol, res + n, -1);
+    bad = ls->solve(ls, res);
+    for (c_int k = 0; k < N; k++) sol[k] += res[k];
+  }
+  if (bad) { w->info->status_polish = -1; goto cleanup; }
+  memcpy(p->x, sol, (size_t)n * sizeof(c_float));
+  for (c_int i = 0; i < m; i++) p->z[i] = 0.0;
+  host_spmv(A, p->x, p->z, +1);
+  for (c_int i = 0; i < m; i++) {
+    if (mred == 0) p->y[i] = 0.0;
+    else if (p->A_to_Alow[i] != -1) p->y[i] = sol[n + p->A_to_Alow[i]];
+    else if (p->A_to_Aupp[i] != -1) p->y[i] = sol[n + p->n_low + p->A_to_Aupp[i]];
+    else p->y[i] = 0.0;
+  }
+  for (c_int i = 0; i < m; i++) {   /* proj.c:16-29 */
+    c_float t = p->z[i] + p->y[i];
+    p->z[i] = HMIN(HMAX(t, w->data->l[i]), w->data->u[i]);
+    p->y[i] = t - p->z[i];
+  }
+  /* residuals of the polished point, evaluated on the device */
+  {
+    hipeng_scalars keep = s->sc, sc;
+    if (hipeng_set_iterates(s->eng, p->x, p->y) || hipeng_set_z(s->eng, p->z) ||
+        hipeng_residuals(s->eng, &sc)) { w->info->status_polish = -1; goto restore; }
+    p->obj_val = sc.obj_scaled * (w->settings->scaling ? w->scaling->cinv : 1.0);
+    p->pri_res = m == 0 ? 0. : (use_unscaled(w) ? sc.pri_res_u : sc.pri_res_s);
+    p->dua_res = use_unscaled(w) ? w->scaling->cinv * sc.dua_res_u : sc.dua_res_s;
+    w->info->polish_time = toc(w->timer);
+    c_int ok = (p->pri_res < w->info->pri_res && p->dua_res < w->info->dua_res) ||
+               (p->pri_res < w->info->pri_res && w->info->dua_res < 1e-10) ||
+               (p->dua_res < w->info->dua_res && w->info->pri_res < 1e-10);
+    if (ok) {
+      w->info->obj_val = p->obj_val; w->info->pri_res = p->pri_res; w->info->dua_res = p->dua_res;
+      w->info->status_polish = 1;
+      memcpy(w->x, p->x, (size_t)n * sizeof(c_float));
+      if (m) { memcpy(w->z, p->z, (size_t)m * sizeof(c_float)); memcpy(w->y, p->y, (size_t)m * sizeof(c_float)); }
+      memcpy(w->solution->x, w->x, (size_t)n * sizeof(c_float));
+      if (m) memcpy(w->solution->y, w->y, (size_t)m * sizeof(c_float));
+      if (w->settings->scaling) {
+        for (c_int j = 0; j < n; j++) w->solution->x[j] = w->solution->x[j] * w->scaling->D[j];
+        for (c_int i = 0; i < m; i++) { w->solution->y[i] = w->solution->y[i] * w->scaling->E[i]; w->solution->y[i] *= w->scaling->cinv; }
+      }
+      s->sc = sc;
+      goto cleanup;
+    }
+    w->info->status_polish = -1;
+    s->sc = keep;
+  }
+restore:   /* put the ADMM iterates back on the device */
+  hipeng_set_iterates(s->eng, w->x, w->y);
+  hipeng_set_z(s->eng, w->z);
+cleanup:
+  w->info->polish_time = toc(w->timer);
+  ls->free(ls);
+  free_csc(Ar); p->Ared = NULL;
+  free(rhs); free(sol); free(res);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* engine access for tests / bench                                            */
+/* ------------------------------------------------------------------------ */
+c_int osqp_amd_get_stats(const OSQPWorkspace *w, osqp_amd_stats *out) {
+  if (!w || !w->linsys_solver || !out) return 1;
+  hip_pcg_solver *s = PCG(w);
+  hipeng_stats hs;
+  if (hipeng_get_stats(s->eng, &hs)) return 1;
+  out->pcg_iters_total = hs.pcg_iters_total; out->pcg_iters_last = hs.pcg_iters_last;
+  out->pcg_forced = hs.pcg_forced; out->graph_launches = hs.graph_launches;
+  out->host_syncs = s->host_syncs;
+  return 0;
+}
+
+void *osqp_amd_engine(const OSQPWorkspace *w) {
+  if (!w || !w->linsys_solver) return NULL;
+  return PCG(w)->eng;
+}
