@@ -9,8 +9,9 @@ import ctypes as C
 from . import _abi as abi
 from ._lib import lib, build, LIB_PATH
 from .interface import SolverHandle, Results
+from .batch import BatchOSQP
 
-__all__ = ["OSQP", "abi", "lib", "build", "engine_options", "set_engine_options"]
+__all__ = ["OSQP", "BatchOSQP", "abi", "lib", "build", "engine_options", "set_engine_options"]
 
 
 class _Options(C.Structure):

@@ -1,0 +1,112 @@
+"""Batched solves of many small QPs with a shared sparsity pattern (MPC-style,
+BASELINE config 4) -- ctypes plumbing over include/osqp_amd_batch.h.  One
+workgroup per QP on the GPU; see osqp_amd/csrc/batch.hip."""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+from scipy import sparse
+
+from . import _abi as abi
+from ._lib import lib
+
+INFO_FIELDS = ["iter", "status_val", "obj_val", "pri_res", "dua_res", "rho_updates", "rho_estimate", "rho"]
+
+
+def _bind(L):
+    H = C.c_void_p
+    L.osqp_amd_batch_setup.restype = abi.c_int
+    L.osqp_amd_batch_setup.argtypes = [C.POINTER(H), abi.c_int, C.POINTER(abi.csc), C.POINTER(abi.csc),
+                                       abi.c_float_p, abi.c_float_p, abi.c_float_p, abi.c_float_p,
+                                       abi.c_float_p, C.POINTER(abi.OSQPSettings), abi.c_int]
+    L.osqp_amd_batch_update.restype = abi.c_int
+    L.osqp_amd_batch_update.argtypes = [H, abi.c_float_p, abi.c_float_p, abi.c_float_p]
+    L.osqp_amd_batch_solve.restype = abi.c_int
+    L.osqp_amd_batch_solve.argtypes = [H]
+    L.osqp_amd_batch_get.restype = abi.c_int
+    L.osqp_amd_batch_get.argtypes = [H, abi.c_float_p, abi.c_float_p, abi.c_float_p, abi.c_float_p, abi.c_float_p]
+    L.osqp_amd_batch_cleanup.restype = None
+    L.osqp_amd_batch_cleanup.argtypes = [H]
+
+
+def _p(a):
+    return C.cast(None, abi.c_float_p) if a is None else abi.fptr(a)
+
+
+class BatchOSQP:
+    def __init__(self):
+        self._lib = lib()
+        _bind(self._lib)
+        self._h = None
+
+    def setup(self, P, A, Q, L, U, Px_all=None, Ax_all=None, device=None, **settings):
+        """P (n x n, any triangle content; upper triangle is used), A (m x n): shared
+        pattern/values.  Q [B, n], L, U [B, m].  Px_all / Ax_all [B, nnz] optional
+        per-QP values in CSC order of triu(P) / A."""
+        from . import engine_options
+        self.Pu = abi.CscHolder(sparse.triu(P, format="csc"))
+        self.Ah = abi.CscHolder(A)
+        Q = abi.as_f64(Q)
+        self.B, self.n = Q.shape
+        self.m = self.Ah.m
+        L = np.maximum(abi.as_f64(L), -abi.OSQP_INFTY)
+        U = np.minimum(abi.as_f64(U), abi.OSQP_INFTY)
+        assert L.shape == U.shape == (self.B, self.m) and self.Pu.n == self.n
+        st = abi.OSQPSettings()
+        self._lib.osqp_set_default_settings.restype = None
+        self._lib.osqp_set_default_settings.argtypes = [C.POINTER(abi.OSQPSettings)]
+        self._lib.osqp_set_default_settings(C.byref(st))
+        st.verbose = 0
+        for k, v in settings.items():
+            if k not in abi.SETTING_NAMES:
+                raise ValueError("unknown setting %r" % k)
+            setattr(st, k, v)
+        if Px_all is not None:
+            Px_all = abi.as_f64(Px_all)
+        if Ax_all is not None:
+            Ax_all = abi.as_f64(Ax_all)
+        if device is None:
+            device = engine_options()["device"]
+        h = C.c_void_p()
+        rc = self._lib.osqp_amd_batch_setup(C.byref(h), self.B, C.byref(self.Pu.struct), C.byref(self.Ah.struct),
+                                            _p(Px_all), _p(Ax_all), abi.fptr(Q), _p(L if self.m else None),
+                                            _p(U if self.m else None), C.byref(st), device)
+        if rc:
+            raise ValueError("osqp_amd_batch_setup failed with error %d" % rc)
+        self._h = h
+        return self
+
+    def update(self, Q=None, L=None, U=None):
+        Q = None if Q is None else abi.as_f64(Q)
+        L = None if L is None else np.maximum(abi.as_f64(L), -abi.OSQP_INFTY)
+        U = None if U is None else np.minimum(abi.as_f64(U), abi.OSQP_INFTY)
+        return int(self._lib.osqp_amd_batch_update(self._h, _p(Q), _p(L), _p(U)))
+
+    def solve(self, fetch=True):
+        rc = self._lib.osqp_amd_batch_solve(self._h)
+        if rc:
+            raise RuntimeError("osqp_amd_batch_solve failed (%d)" % rc)
+        return self.results() if fetch else None
+
+    def results(self):
+        X = np.zeros((self.B, self.n)); Y = np.zeros((self.B, max(self.m, 1)))
+        info = np.zeros((self.B, 8)); DX = np.zeros((self.B, self.n)); DY = np.zeros((self.B, max(self.m, 1)))
+        rc = self._lib.osqp_amd_batch_get(self._h, abi.fptr(X), abi.fptr(Y), abi.fptr(info), abi.fptr(DX), abi.fptr(DY))
+        if rc:
+            raise RuntimeError("osqp_amd_batch_get failed (%d)" % rc)
+        out = SimpleNamespace(x=X, y=Y[:, :self.m], dual_inf_cert=DX, prim_inf_cert=DY[:, :self.m], info_raw=info)
+        for k, name in enumerate(INFO_FIELDS):
+            col = info[:, k]
+            setattr(out, name, col.astype(np.int64) if name in ("iter", "status_val", "rho_updates") else col)
+        return out
+
+    def cleanup(self):
+        if self._h is not None:
+            self._lib.osqp_amd_batch_cleanup(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass

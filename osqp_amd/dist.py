@@ -1,0 +1,44 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" is
+RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+
+The only path that shards is the batch of independent QPs: contiguous blocks of
+ceil(B / world) problems per rank, no communication during the solves, and ONE
+all_gather of the per-QP records [x | y | info8] at the end.
+A single QP does not shard; `bench.py --gpus N` runs replicas."""
+import numpy as np
+
+
+def shard_range(batch, rank, world):
+    per = (batch + world - 1) // world
+    lo = min(batch, rank * per)
+    hi = min(batch, lo + per)
+    return lo, hi, per
+
+
+def sharded_batch_solve(local_solve, Q, L, U, group=None, device=None):
+    """local_solve(Q_shard, L_shard, U_shard) -> (X, Y, info8) numpy arrays for the
+    rank's shard.  Returns the gathered (X, Y, info8) of the whole batch on every
+    rank.  `device` = torch device for the gather buffers (cuda for nccl)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B, n = Q.shape
+    m = L.shape[1]
+    lo, hi, per = shard_range(B, rank, world)
+    X, Y, info = local_solve(Q[lo:hi], L[lo:hi], U[lo:hi])
+    rec = np.zeros((per, n + m + 8))
+    rec[:hi - lo, :n] = X
+    rec[:hi - lo, n:n + m] = Y
+    rec[:hi - lo, n + m:] = info
+    if world == 1:
+        full = rec
+    else:
+        t = torch.from_numpy(rec)
+        if device is not None:
+            t = t.to(device)
+        out = torch.empty((world * per, n + m + 8), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=group)
+        full = out.cpu().numpy()
+    full = full[:B]
+    return full[:, :n], full[:, n:n + m], full[:, n + m:]

@@ -137,7 +137,7 @@ def mpc_batch(batch=1024, N=12, seed0=0):
     U = np.zeros((batch, s["m"]))
     for b in range(batch):
         rng = np.random.default_rng(seed0 + b)
-        x0 = rng.standard_normal(s["nx"])
+        x0 = 0.5 * rng.standard_normal(s["nx"])
         Q[b], L[b], U[b] = s["vectors"](x0)
     return s, Q, L, U
 
