@@ -1,14 +1,14 @@
 // batch.hip -- batched OSQP engine for many small QPs with one sparsity pattern
 // (MPC-style: BASELINE config 4, 1024 x (n=120, m=240)), gfx950 / MI355X.
 //
-// One 256-thread workgroup solves one QP from raw data to unscaled solution in
+// One 512-thread workgroup solves one QP from raw data to unscaled solution in
 // a single kernel launch; the grid is the batch.  Nothing leaves the CU during
 // the ADMM loop:
 //   * problem vectors and the (per-QP) scaled matrix values live in LDS;
 //   * the KKT solve of update_xz_tilde (reference src/auxil.c:177-183) is a
 //     direct one: K = P + sigma I + A' diag(rho) A (n x n, SPD) is formed and
 //     inverted in place by Gauss-Jordan with the matrix held in REGISTERS,
-//     tiled TILE x TILE over a 16 x 16 thread grid (n <= 16*TILE); every ADMM
+//     tiled TR x TC over a 16 x 32 thread grid (n <= 16*TR = 32*TC); every ADMM
 //     iteration is then one register-tile GEMV (+ one step of iterative
 //     refinement through the sparse operator) -- the per-QP analogue of the
 //     reference's factor-once / solve-many LDL^T (qdldl_interface.c:341-376),
@@ -30,7 +30,7 @@
 #include "../../include/osqp_amd.h"
 #include "../../include/osqp_amd_batch.h"
 
-#define BT 256
+#define BT 512            // 8 wavefronts; thread grid 16 (row blocks) x 32 (column blocks)
 #define BINF 1e26
 
 #define BCHK(call)                                                              \
@@ -49,12 +49,13 @@ struct BPattern {          // shared sparsity (device pointers)
   const int *Fp, *Fi, *Fk;       // full symmetric P by columns: ptr, row, triu slot
   const int *Ap, *Ai, *Ac;       // A CSC: col ptr, row idx, column of each entry
   const int *Rp, *Rj, *Rk;       // A CSR: row ptr, col idx, CSC slot
+  const int *packed;             // all twelve arrays back to back (copied to LDS by the kernel)
 };
 
 struct BSettings {
   double rho, sigma, alpha, eps_abs, eps_rel, eps_pinf, eps_dinf, rho_tol, adapt_tol;
   int scaling, adaptive_rho, rho_interval, max_iter, check_termination, scaled_termination,
-      warm_start, refine;
+      warm_start, refine, profile;
 };
 
 struct BIO {               // per-batch arrays (device)
@@ -86,14 +87,14 @@ __device__ __forceinline__ double b_sum(double v, double *red) {
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+  return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
 }
 __device__ __forceinline__ double b_max(double v, double *red) {
   v = b_wave_max(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  return fmax(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])), fmax(fmax(red[4], red[5]), fmax(red[6], red[7])));
 }
 __device__ __forceinline__ double clip_scale(double v) {
   if (v < 1e-4) v = 1.0;
@@ -101,104 +102,144 @@ __device__ __forceinline__ double clip_scale(double v) {
   return v;
 }
 
-// LDS working set of one QP
+// LDS working set of one QP.  n-vectors are NP apart, m-vectors m apart, index
+// arrays are one int block: a handful of base pointers instead of ~40.
 struct BL {
-  double *Pv, *Av;                                  // scaled matrix values (triu P, CSC A)
-  double *q, *l, *u, *rho, *rinv, *x, *z, *y, *xt, *zt, *w, *dx, *dy, *D, *E, *tn, *tm, *b;
-  double *rowk, *colk;                              // Gauss-Jordan exchange (2 x 2 x NP)
+  double *Pv, *Av;          // scaled matrix values (triu P, CSC A)
+  double *nv, *mv;          // n-vector block (stride NP), m-vector block (stride m)
+  double *rowk, *colk;      // Gauss-Jordan exchange (2 x 2 x NP)
   double *red;
   int *ctype;
+  int NP, m;
+  // shared sparsity pattern, copied into LDS once per workgroup
+  const int *Pp, *Pi, *Pc, *Fp, *Fi, *Fk, *Ap, *Ai, *Ac, *Rp, *Rj, *Rk;
 };
+#define NV(k) (s.nv + (k) * s.NP)
+#define MV(k) (s.mv + (k) * s.m)
+#define s_q NV(0)
+#define s_x NV(1)
+#define s_xt NV(2)
+#define s_dx NV(3)
+#define s_D NV(4)
+#define s_tn NV(5)
+#define s_b NV(6)
+#define s_l MV(0)
+#define s_u MV(1)
+#define s_rho MV(2)
+#define s_rinv MV(3)
+#define s_z MV(4)
+#define s_y MV(5)
+#define s_zt MV(6)
+#define s_w MV(7)
+#define s_dy MV(8)
+#define s_E MV(9)
+#define s_tm MV(10)
 
 // y_i = sum_j A_ij v_j  (row gather through the CSR view of the CSC values)
-__device__ __forceinline__ double a_row_dot(const BPattern &p, const double *Av, const double *v, int i) {
-  double s = 0.0;
-  for (int k = p.Rp[i]; k < p.Rp[i + 1]; ++k) s += Av[p.Rk[k]] * v[p.Rj[k]];
-  return s;
+__device__ __forceinline__ double a_row_dot(const BL &s, const double *v, int i) {
+  double acc = 0.0;
+  for (int k = s.Rp[i]; k < s.Rp[i + 1]; ++k) acc += s.Av[s.Rk[k]] * v[s.Rj[k]];
+  return acc;
 }
 // (A' v)_j  (column gather)
-__device__ __forceinline__ double a_col_dot(const BPattern &p, const double *Av, const double *v, int j) {
-  double s = 0.0;
-  for (int k = p.Ap[j]; k < p.Ap[j + 1]; ++k) s += Av[k] * v[p.Ai[k]];
-  return s;
+__device__ __forceinline__ double a_col_dot(const BL &s, const double *v, int j) {
+  double acc = 0.0;
+  for (int k = s.Ap[j]; k < s.Ap[j + 1]; ++k) acc += s.Av[k] * v[s.Ai[k]];
+  return acc;
 }
 // (P v)_j from the full symmetric pattern
-__device__ __forceinline__ double p_row_dot(const BPattern &p, const double *Pv, const double *v, int j) {
-  double s = 0.0;
-  for (int k = p.Fp[j]; k < p.Fp[j + 1]; ++k) s += Pv[p.Fk[k]] * v[p.Fi[k]];
-  return s;
+__device__ __forceinline__ double p_row_dot(const BL &s, const double *v, int j) {
+  double acc = 0.0;
+  for (int k = s.Fp[j]; k < s.Fp[j + 1]; ++k) acc += s.Pv[s.Fk[k]] * v[s.Fi[k]];
+  return acc;
 }
 
 // ---------------------------------------------------------------------------
 // register-tiled K^-1: thread (tr, tc) of a 16 x 16 grid owns rows tr*T.. and
 // columns tc*T.. of the (padded) NP x NP matrix, NP = 16*T.
 // ---------------------------------------------------------------------------
-template <int T>
-__device__ void form_K(double (&a)[T][T], const BPattern &p, const BL &s, double sigma) {
-  const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
-#pragma unroll
-  for (int r = 0; r < T; ++r)
-#pragma unroll
-    for (int c = 0; c < T; ++c) {
-      const int i = tr * T + r, j = tc * T + c;
-      double v = 0.0;
-      if (i < p.n && j < p.n) {
+template <int TR, int TC>
+__device__ __forceinline__ void form_K(double (&a)[TR][TC], int n, const BL &s, double sigma) {
+  const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
+  const double *rho = s_rho;
+#pragma unroll 1
+  for (int r = 0; r < TR; ++r) {
+    double v[TC];
+#pragma unroll 1
+    for (int c = 0; c < TC; ++c) {
+      const int i = tr * TR + r, j = tc * TC + c;
+      double acc = 0.0;
+      if (i < n && j < n) {
         // P_ij from the upper triangle: column max(i,j), row min(i,j)
         const int cj = i > j ? i : j, ri = i > j ? j : i;
-        for (int k = p.Pp[cj]; k < p.Pp[cj + 1]; ++k) if (p.Pi[k] == ri) v += s.Pv[k];
-        if (i == j) v += sigma;
+        for (int k = s.Pp[cj]; k < s.Pp[cj + 1]; ++k) if (s.Pi[k] == ri) acc += s.Pv[k];
+        if (i == j) acc += sigma;
         // sum_t rho_t A_ti A_tj : merge of the two sorted columns
-        int ka = p.Ap[i], kb = p.Ap[j];
-        const int ea = p.Ap[i + 1], eb = p.Ap[j + 1];
+        int ka = s.Ap[i], kb = s.Ap[j];
+        const int ea = s.Ap[i + 1], eb = s.Ap[j + 1];
         while (ka < ea && kb < eb) {
-          const int ra = p.Ai[ka], rb = p.Ai[kb];
-          if (ra == rb) { v += s.rho[ra] * s.Av[ka] * s.Av[kb]; ++ka; ++kb; }
+          const int ra = s.Ai[ka], rb = s.Ai[kb];
+          if (ra == rb) { acc += rho[ra] * s.Av[ka] * s.Av[kb]; ++ka; ++kb; }
           else if (ra < rb) ++ka; else ++kb;
         }
-      } else if (i == j) v = 1.0;      // identity padding keeps the inverse well defined
-      a[r][c] = v;
+      } else if (i == j) acc = 1.0;    // identity padding keeps the inverse well defined
+#pragma unroll
+      for (int cc = 0; cc < TC; ++cc) if (cc == c) v[cc] = acc;
     }
+#pragma unroll
+    for (int rr = 0; rr < TR; ++rr)
+#pragma unroll
+      for (int cc = 0; cc < TC; ++cc) if (rr == r) a[rr][cc] = v[cc];
+  }
 }
 
 // In-place Gauss-Jordan inversion without pivoting (K is SPD).  One barrier per
 // pivot: the pivot row / column are exchanged through double-buffered LDS.
-template <int T>
-__device__ void invert_tiles(double (&a)[T][T], const BL &s) {
-  constexpr int NP = 16 * T;
-  const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
-  for (int k = 0; k < NP; ++k) {
-    double *rowk = s.rowk + (k & 1) * NP, *colk = s.colk + (k & 1) * NP;
-    const int kb = k / T, ko = k % T;
-    if (tr == kb) {
+template <int TR, int TC>
+__device__ __forceinline__ void invert_tiles(double (&a)[TR][TC], const BL &s) {
+  // The pivot loop is unrolled by TR (a multiple of TC) so that the pivot's
+  // position inside a tile (ko, kco) is a compile-time constant: the register
+  // tile is only ever indexed statically.  Per pivot: owners publish row k and
+  // column k to LDS, one barrier, one FMA per tile element, then the owners of
+  // row k / column k overwrite their strip with the Gauss-Jordan special cases.
+  static_assert(TR % TC == 0, "tile shape");
+  constexpr int NP = 16 * TR;
+  const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
+#pragma unroll 1
+  for (int kb = 0; kb < 16; ++kb) {
 #pragma unroll
-      for (int c = 0; c < T; ++c) {
-        double v = 0;
+    for (int ko = 0; ko < TR; ++ko) {
+      constexpr int dummy = 0; (void)dummy;
+      const int k = kb * TR + ko;
+      const int kco = ko % TC;               // static after unrolling
+      const int kc = k / TC;                 // column block that owns column k
+      double *rowk = s.rowk + (k & 1) * NP, *colk = s.colk + (k & 1) * NP;
+      if (tr == kb) {
 #pragma unroll
-        for (int r = 0; r < T; ++r) if (r == ko) v = a[r][c];
-        rowk[tc * T + c] = v;
+        for (int c = 0; c < TC; ++c) rowk[tc * TC + c] = a[ko][c];
       }
-    }
-    if (tc == kb) {
+      if (tc == kc) {
 #pragma unroll
-      for (int r = 0; r < T; ++r) {
-        double v = 0;
-#pragma unroll
-        for (int c = 0; c < T; ++c) if (c == ko) v = a[r][c];
-        colk[tr * T + r] = v;
+        for (int r = 0; r < TR; ++r) colk[tr * TR + r] = a[r][kco];
       }
-    }
-    __syncthreads();
-    const double piv = 1.0 / rowk[k];
+      __syncthreads();
+      const double piv = 1.0 / rowk[k];
+      double rk[TC];
 #pragma unroll
-    for (int r = 0; r < T; ++r) {
-      const int i = tr * T + r;
-      const double ci = colk[i];
+      for (int c = 0; c < TC; ++c) rk[c] = rowk[tc * TC + c] * piv;
 #pragma unroll
-      for (int c = 0; c < T; ++c) {
-        const int j = tc * T + c;
-        const double rkj = (j == k) ? piv : rowk[j] * piv;
-        if (i == k) a[r][c] = rkj;
-        else a[r][c] = ((j == k) ? 0.0 : a[r][c]) - ci * rkj;
+      for (int r = 0; r < TR; ++r) {
+        const double ci = colk[tr * TR + r];
+#pragma unroll
+        for (int c = 0; c < TC; ++c) a[r][c] = a[r][c] - ci * rk[c];
+      }
+      if (tc == kc) {          // column k: a_ik <- -a_ik / a_kk
+#pragma unroll
+        for (int r = 0; r < TR; ++r) a[r][kco] = 0.0 - colk[tr * TR + r] * piv;
+      }
+      if (tr == kb) {          // row k: a_kj <- a_kj / a_kk, a_kk <- 1 / a_kk
+#pragma unroll
+        for (int c = 0; c < TC; ++c) a[ko][c] = (tc * TC + c == k) ? piv : rk[c];
       }
     }
   }
@@ -206,31 +247,31 @@ __device__ void invert_tiles(double (&a)[T][T], const BL &s) {
 }
 
 // out_i = sum_j Kinv_ij in_j ; in / out are LDS vectors of length >= NP
-template <int T>
-__device__ void tile_gemv(const double (&a)[T][T], const double *in, double *out) {
-  const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
-  double bj[T], acc[T];
+template <int TR, int TC>
+__device__ __forceinline__ void tile_gemv(const double (&a)[TR][TC], const double *in, double *out) {
+  const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
+  double bj[TC], acc[TR];
 #pragma unroll
-  for (int c = 0; c < T; ++c) bj[c] = in[tc * T + c];
+  for (int c = 0; c < TC; ++c) bj[c] = in[tc * TC + c];
 #pragma unroll
-  for (int r = 0; r < T; ++r) {
+  for (int r = 0; r < TR; ++r) {
     double v = 0.0;
 #pragma unroll
-    for (int c = 0; c < T; ++c) v += a[r][c] * bj[c];
+    for (int c = 0; c < TC; ++c) v += a[r][c] * bj[c];
     acc[r] = v;
   }
-  // fixed xor tree over the 16 lanes that share a row block
+  // fixed xor tree over the 32 lanes that share a row block
 #pragma unroll
-  for (int r = 0; r < T; ++r) {
+  for (int r = 0; r < TR; ++r) {
     double v = acc[r];
-    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);  v += __shfl_xor(v, 1, 64);
     acc[r] = v;
   }
   __syncthreads();            // readers of `out`'s previous contents are done
   if (tc == 0) {
 #pragma unroll
-    for (int r = 0; r < T; ++r) out[tr * T + r] = acc[r];
+    for (int r = 0; r < TR; ++r) out[tr * TR + r] = acc[r];
   }
   __syncthreads();
 }
@@ -238,278 +279,343 @@ __device__ void tile_gemv(const double (&a)[T][T], const double *in, double *out
 // ---------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------
-template <int T>
+template <int TR, int TC>
 __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BIO io, int first_solve) {
-  constexpr int NP = 16 * T;
+  constexpr int NP = 16 * TR;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int n = p.n, m = p.m, tid = threadIdx.x;
   const long long qp = blockIdx.x;
   BL s;
   {
     double *w = lds;
+    s.NP = NP; s.m = m;
     s.Pv = w; w += p.nnzP; s.Av = w; w += p.nnzA;
-    s.q = w; w += NP; s.x = w; w += NP; s.xt = w; w += NP; s.dx = w; w += NP; s.D = w; w += NP;
-    s.tn = w; w += NP; s.b = w; w += NP;
-    s.l = w; w += m; s.u = w; w += m; s.rho = w; w += m; s.rinv = w; w += m; s.z = w; w += m;
-    s.y = w; w += m; s.zt = w; w += m; s.w = w; w += m; s.dy = w; w += m; s.E = w; w += m; s.tm = w; w += m;
-    s.rowk = w; w += 2 * NP; s.colk = w; w += 2 * NP; s.red = w; w += 8;
-    s.ctype = reinterpret_cast<int *>(w);
+    s.nv = w; w += 7 * NP; s.mv = w; w += 11 * m;
+    s.rowk = w; w += 2 * NP; s.colk = w; w += 2 * NP; s.red = w; w += 32;
+    int *iw = reinterpret_cast<int *>(w);
+    s.ctype = iw; iw += m;
+    int *ib = iw;
+    s.Pp = iw; iw += n + 1; s.Pi = iw; iw += p.nnzP; s.Pc = iw; iw += p.nnzP;
+    s.Fp = iw; iw += n + 1; s.Fi = iw; iw += p.nnzPf; s.Fk = iw; iw += p.nnzPf;
+    s.Ap = iw; iw += n + 1; s.Ai = iw; iw += p.nnzA; s.Ac = iw; iw += p.nnzA;
+    s.Rp = iw; iw += m + 1; s.Rj = iw; iw += p.nnzA; s.Rk = iw; iw += p.nnzA;
+    // the host packs the twelve index arrays back to back in this order
+    const int tot = (int)(iw - ib);
+    for (int k = tid; k < tot; k += BT) ib[k] = p.packed[k];
   }
-  double a[T][T];
+  double a[TR][TC];
+  unsigned long long tstamp[8];
+  tstamp[0] = wall_clock64();
 
   // ---- load the problem -----------------------------------------------------
   const double *Pg = io.Px + qp * io.strideP, *Ag = io.Ax + qp * io.strideA;
   for (int k = tid; k < p.nnzP; k += BT) s.Pv[k] = Pg[k];
   for (int k = tid; k < p.nnzA; k += BT) s.Av[k] = Ag[k];
   for (int j = tid; j < NP; j += BT) {
-    s.q[j] = j < n ? io.Q[qp * n + j] : 0.0;
-    s.x[j] = 0.0; s.xt[j] = 0.0; s.dx[j] = 0.0; s.D[j] = 1.0; s.tn[j] = 0.0; s.b[j] = 0.0;
+    s_q[j] = j < n ? io.Q[qp * n + j] : 0.0;
+    s_x[j] = 0.0; s_xt[j] = 0.0; s_dx[j] = 0.0; s_D[j] = 1.0; s_tn[j] = 0.0; s_b[j] = 0.0;
   }
   for (int i = tid; i < m; i += BT) {
-    s.l[i] = io.L[qp * m + i]; s.u[i] = io.U[qp * m + i];
-    s.z[i] = 0.0; s.y[i] = 0.0; s.E[i] = 1.0; s.dy[i] = 0.0; s.zt[i] = 0.0;
+    s_l[i] = io.L[qp * m + i]; s_u[i] = io.U[qp * m + i];
+    s_z[i] = 0.0; s_y[i] = 0.0; s_E[i] = 1.0; s_dy[i] = 0.0; s_zt[i] = 0.0;
   }
   __syncthreads();
 
+  tstamp[1] = wall_clock64();
   // ---- Ruiz equilibration (scaling.c:44-156), per QP -------------------------
   double cs = 1.0;   // cost scaling c
   for (int pass = 0; pass < st.scaling; ++pass) {
     for (int j = tid; j < n; j += BT) {
       double v = 0.0;
-      for (int k = p.Fp[j]; k < p.Fp[j + 1]; ++k) v = fmax(v, fabs(s.Pv[p.Fk[k]]));
-      for (int k = p.Ap[j]; k < p.Ap[j + 1]; ++k) v = fmax(v, fabs(s.Av[k]));
-      s.tn[j] = 1.0 / sqrt(clip_scale(v));
+      for (int k = s.Fp[j]; k < s.Fp[j + 1]; ++k) v = fmax(v, fabs(s.Pv[s.Fk[k]]));
+      for (int k = s.Ap[j]; k < s.Ap[j + 1]; ++k) v = fmax(v, fabs(s.Av[k]));
+      s_tn[j] = 1.0 / sqrt(clip_scale(v));
     }
     for (int i = tid; i < m; i += BT) {
       double v = 0.0;
-      for (int k = p.Rp[i]; k < p.Rp[i + 1]; ++k) v = fmax(v, fabs(s.Av[p.Rk[k]]));
-      s.tm[i] = 1.0 / sqrt(clip_scale(v));
+      for (int k = s.Rp[i]; k < s.Rp[i + 1]; ++k) v = fmax(v, fabs(s.Av[s.Rk[k]]));
+      s_tm[i] = 1.0 / sqrt(clip_scale(v));
     }
     __syncthreads();
-    for (int k = tid; k < p.nnzP; k += BT) s.Pv[k] = (s.Pv[k] * s.tn[p.Pi[k]]) * s.tn[p.Pc[k]];
-    for (int k = tid; k < p.nnzA; k += BT) s.Av[k] = (s.Av[k] * s.tm[p.Ai[k]]) * s.tn[p.Ac[k]];
-    for (int j = tid; j < n; j += BT) { s.q[j] = s.q[j] * s.tn[j]; s.D[j] = s.tn[j] * s.D[j]; }
-    for (int i = tid; i < m; i += BT) s.E[i] = s.tm[i] * s.E[i];
+    for (int k = tid; k < p.nnzP; k += BT) s.Pv[k] = (s.Pv[k] * s_tn[s.Pi[k]]) * s_tn[s.Pc[k]];
+    for (int k = tid; k < p.nnzA; k += BT) s.Av[k] = (s.Av[k] * s_tm[s.Ai[k]]) * s_tn[s.Ac[k]];
+    for (int j = tid; j < n; j += BT) { s_q[j] = s_q[j] * s_tn[j]; s_D[j] = s_tn[j] * s_D[j]; }
+    for (int i = tid; i < m; i += BT) s_E[i] = s_tm[i] * s_E[i];
     __syncthreads();
     // cost normalisation: mean column norm of P (sequential sum, reference order) vs |q|_inf
     double cn = 0.0, qn = 0.0;
     for (int j = tid; j < n; j += BT) {
       double v = 0.0;
-      for (int k = p.Fp[j]; k < p.Fp[j + 1]; ++k) v = fmax(v, fabs(s.Pv[p.Fk[k]]));
-      s.tn[j] = v;
-      qn = fmax(qn, fabs(s.q[j]));
+      for (int k = s.Fp[j]; k < s.Fp[j + 1]; ++k) v = fmax(v, fabs(s.Pv[s.Fk[k]]));
+      s_tn[j] = v;
+      qn = fmax(qn, fabs(s_q[j]));
     }
     qn = b_max(qn, s.red);
-    if (tid == 0) { double acc = 0.0; for (int j = 0; j < n; ++j) acc += s.tn[j]; s.red[6] = acc / (double)n; }
+    if (tid == 0) { double acc = 0.0; for (int j = 0; j < n; ++j) acc += s_tn[j]; s.red[6] = acc / (double)n; }
     __syncthreads();
     cn = s.red[6];
     double ct = fmax(cn, clip_scale(qn));
     ct = 1.0 / clip_scale(ct);
     for (int k = tid; k < p.nnzP; k += BT) s.Pv[k] *= ct;
-    for (int j = tid; j < n; j += BT) s.q[j] *= ct;
+    for (int j = tid; j < n; j += BT) s_q[j] *= ct;
     cs *= ct;
     __syncthreads();
   }
   const double cinv = 1.0 / cs;
   const bool unscaled = st.scaling && !st.scaled_termination;
-  for (int i = tid; i < m; i += BT) { s.l[i] = s.l[i] * s.E[i]; s.u[i] = s.u[i] * s.E[i]; }
+  for (int i = tid; i < m; i += BT) { s_l[i] = s_l[i] * s_E[i]; s_u[i] = s_u[i] * s_E[i]; }
   __syncthreads();
 
+  tstamp[2] = wall_clock64();
   // ---- rho vector (auxil.c:76-98) and warm start -----------------------------
   double rho = (first_solve || !io.rho_io) ? st.rho : io.rho_io[qp];
   rho = fmin(fmax(rho, 1e-6), 1e6);
   for (int i = tid; i < m; i += BT) {
     int t = 0;
-    if (s.l[i] < -BINF && s.u[i] > BINF) t = -1;
-    else if (s.u[i] - s.l[i] < st.rho_tol) t = 1;
+    if (s_l[i] < -BINF && s_u[i] > BINF) t = -1;
+    else if (s_u[i] - s_l[i] < st.rho_tol) t = 1;
     s.ctype[i] = t;
     const double r = t == -1 ? 1e-6 : (t == 1 ? 1e3 * rho : rho);
-    s.rho[i] = r; s.rinv[i] = 1.0 / r;
+    s_rho[i] = r; s_rinv[i] = 1.0 / r;
   }
   if (st.warm_start && !first_solve) {
-    for (int j = tid; j < n; j += BT) s.x[j] = io.Xs[qp * n + j];
-    for (int i = tid; i < m; i += BT) { s.z[i] = io.Zs[qp * m + i]; s.y[i] = io.Ys[qp * m + i]; }
+    for (int j = tid; j < n; j += BT) s_x[j] = io.Xs[qp * n + j];
+    for (int i = tid; i < m; i += BT) { s_z[i] = io.Zs[qp * m + i]; s_y[i] = io.Ys[qp * m + i]; }
   }
   __syncthreads();
-  form_K<T>(a, p, s, st.sigma);
-  invert_tiles<T>(a, s);
+  tstamp[3] = wall_clock64();
+  form_K<TR, TC>(a, n, s, st.sigma);
+  tstamp[4] = wall_clock64();
+  invert_tiles<TR, TC>(a, s);
+  tstamp[5] = wall_clock64();
 
   // ---- ADMM loop (osqp.c:354-532) ---------------------------------------------
+  // Uniform scalars (norms, residuals, status) live in LDS (`sc`), not in
+  // registers, and the residual/termination code has ONE call site: a small
+  // stage machine replaces the reference's in-loop / post-loop / approximate
+  // calls of update_info + check_termination (osqp.c:411-437, 537-581).
   const double alpha = st.alpha, oma = 1.0 - st.alpha, sigma = st.sigma;
-  int iter = 0, status = OSQP_UNSOLVED, rho_updates = 0;
-  double pri_res = 0, dua_res = 0, obj = 0, rho_est = rho;
-  // scaled norms of the last residual evaluation (for the rho estimate)
-  double n_pri_s = 0, n_dua_s = 0, n_z_s = 0, n_ax_s = 0, n_q_s = 0, n_aty_s = 0, n_px_s = 0;
-  // unscaled (or scaled, when no unscaling) norms for the tolerances
-  double n_z = 0, n_ax = 0, n_q = 0, n_aty = 0, n_px = 0;
+  double *sc = s.red + 8;
+  enum { S_PRI, S_DUA, S_OBJ, S_NPRI_S, S_NDUA_S, S_NZ_S, S_NAX_S, S_NQ_S, S_NATY_S, S_NPX_S,
+         S_NZ, S_NAX, S_NQ, S_NATY, S_NPX, S_STATUS, S_RHO, S_COUNT_ };
+  enum { F_NORMS = 1, F_STATUS = 2, F_APPROX = 4 };
+  if (tid == 0) { for (int k = 0; k < S_COUNT_; ++k) sc[k] = 0.0; sc[S_STATUS] = OSQP_UNSOLVED; sc[S_RHO] = rho; }
+  __syncthreads();
+  int iter = 0, rho_updates = 0, stage = 0;
+  unsigned long long pacc[5] = {0, 0, 0, 0, 0}, pt0 = 0, pt1 = 0;
+#define PSTAMP(slot) do { if (st.profile) { pt1 = wall_clock64(); pacc[slot] += pt1 - pt0; pt0 = pt1; } } while (0)
+  bool norms_fresh = false;
 
-  auto evaluate = [&](bool approximate) -> bool {
-    // ---- update_info: residuals and norms (auxil.c:227-318) ----
-    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
-    for (int i = tid; i < m; i += BT) {
-      const double ax = a_row_dot(p, s.Av, s.x, i);
-      const double pr = ax + (-1.0) * s.z[i];
-      const double ei = unscaled ? 1.0 / s.E[i] : 1.0;
-      s.tm[i] = ax;
-      m0 = fmax(m0, fabs(ei * pr)); m1 = fmax(m1, fabs(pr));
-      m2 = fmax(m2, fabs(ei * s.z[i])); m3 = fmax(m3, fabs(s.z[i]));
-      m4 = fmax(m4, fabs(ei * ax)); m5 = fmax(m5, fabs(ax));
-    }
-    pri_res = m == 0 ? 0.0 : b_max(m0, s.red); n_pri_s = b_max(m1, s.red);
-    n_z = b_max(m2, s.red); n_z_s = b_max(m3, s.red); n_ax = b_max(m4, s.red); n_ax_s = b_max(m5, s.red);
-    double d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, d6 = 0, d7 = 0, ob = 0;
-    for (int j = tid; j < n; j += BT) {
-      const double px = p_row_dot(p, s.Pv, s.x, j);
-      const double aty = a_col_dot(p, s.Av, s.y, j);
-      double dr = s.q[j] + px;
-      if (m > 0) dr = dr + aty;
-      const double di = unscaled ? 1.0 / s.D[j] : 1.0;
-      d0 = fmax(d0, fabs(di * dr)); d1 = fmax(d1, fabs(dr));
-      d2 = fmax(d2, fabs(di * s.q[j])); d3 = fmax(d3, fabs(s.q[j]));
-      d4 = fmax(d4, fabs(di * aty)); d5 = fmax(d5, fabs(aty));
-      d6 = fmax(d6, fabs(di * px)); d7 = fmax(d7, fabs(px));
-      ob += s.x[j] * (0.5 * px + s.q[j]);
-    }
-    dua_res = b_max(d0, s.red); n_dua_s = b_max(d1, s.red);
-    n_q = b_max(d2, s.red); n_q_s = b_max(d3, s.red); n_aty = b_max(d4, s.red); n_aty_s = b_max(d5, s.red);
-    n_px = b_max(d6, s.red); n_px_s = b_max(d7, s.red);
-    obj = b_sum(ob, s.red) * (st.scaling ? cinv : 1.0);
-    if (unscaled) { dua_res *= cinv; n_q *= cinv; n_aty *= cinv; n_px *= cinv; }
-    else { pri_res = m == 0 ? 0.0 : n_pri_s; }
-
-    // ---- check_termination (auxil.c:681-786) ----
-    if (pri_res > 1e30 || dua_res > 1e30) { status = OSQP_NON_CVX; obj = OSQP_NAN; return true; }
-    double ea = st.eps_abs, er = st.eps_rel, epi = st.eps_pinf, edi = st.eps_dinf;
-    if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
-    bool prim_ok = false, dual_ok = false, pinf = false, dinf = false;
-    if (m == 0) prim_ok = true;
-    else if (pri_res < ea + er * fmax(n_z, n_ax)) prim_ok = true;
-    else {
-      // is_primal_infeasible (auxil.c:361-424); dy projected into tm
-      double nd = 0, lhs = 0;
-      for (int i = tid; i < m; i += BT) {
-        double dy = s.dy[i];
-        if (s.u[i] > BINF) { if (s.l[i] < -BINF) dy = 0.0; else dy = fmin(dy, 0.0); }
-        else if (s.l[i] < -BINF) dy = fmax(dy, 0.0);
-        s.w[i] = dy;
-        nd = fmax(nd, fabs(unscaled ? s.E[i] * dy : dy));
-        lhs += s.u[i] * fmax(dy, 0.0) + s.l[i] * fmin(dy, 0.0);
-      }
-      nd = b_max(nd, s.red); lhs = b_sum(lhs, s.red);
-      if (nd > 1e-30 && lhs < epi * nd) {
-        double mx = 0;
-        for (int j = tid; j < n; j += BT) {
-          double v = a_col_dot(p, s.Av, s.w, j);
-          if (unscaled) v = v / s.D[j];
-          mx = fmax(mx, fabs(v));
-        }
-        mx = b_max(mx, s.red);
-        pinf = mx < epi * nd;
-      }
-    }
-    if (dua_res < ea + er * fmax(fmax(n_q, n_aty), n_px)) dual_ok = true;
-    else {
-      // is_dual_infeasible (auxil.c:426-512)
-      double ndx = 0, qdx = 0;
-      for (int j = tid; j < n; j += BT) {
-        ndx = fmax(ndx, fabs(unscaled ? s.D[j] * s.dx[j] : s.dx[j]));
-        qdx += s.q[j] * s.dx[j];
-      }
-      ndx = b_max(ndx, s.red); qdx = b_sum(qdx, s.red);
-      const double csc_ = unscaled ? cs : 1.0;
-      if (ndx > 1e-30 && qdx < csc_ * edi * ndx) {
-        double mx = 0;
-        for (int j = tid; j < n; j += BT) {
-          double v = p_row_dot(p, s.Pv, s.dx, j);
-          if (unscaled) v = v / s.D[j];
-          mx = fmax(mx, fabs(v));
-        }
-        mx = b_max(mx, s.red);
-        if (mx < csc_ * edi * ndx) {
-          double viol = 0;
-          for (int i = tid; i < m; i += BT) {
-            double v = a_row_dot(p, s.Av, s.dx, i);
-            if (unscaled) v = v / s.E[i];
-            if ((s.u[i] < BINF && v > edi * ndx) || (s.l[i] > -BINF && v < -edi * ndx)) viol += 1.0;
-          }
-          viol = b_sum(viol, s.red);
-          dinf = viol == 0.0;
-        }
-      }
-    }
-    if (prim_ok && dual_ok) { status = approximate ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED; return true; }
-    if (pinf) { status = approximate ? OSQP_PRIMAL_INFEASIBLE_INACCURATE : OSQP_PRIMAL_INFEASIBLE; obj = OSQP_INFTY; return true; }
-    if (dinf) { status = approximate ? OSQP_DUAL_INFEASIBLE_INACCURATE : OSQP_DUAL_INFEASIBLE; obj = -OSQP_INFTY; return true; }
-    return false;
-  };
-
-  auto rho_estimate = [&]() -> double {     // auxil.c:13-52
-    const double pr = (m ? n_pri_s : 0.0) / (fmax(n_z_s, n_ax_s) + 1e-30);
-    const double du = n_dua_s / (fmax(fmax(n_q_s, n_aty_s), n_px_s) + 1e-30);
-    return fmin(fmax(rho * sqrt(pr / du), 1e-6), 1e6);
-  };
-
-  bool checked = false;
-  for (iter = 1; iter <= st.max_iter; ++iter) {
-    // rhs of the reduced system: b = sigma x - q + A'(rho z - y)
-    for (int i = tid; i < m; i += BT) s.w[i] = s.rho[i] * s.z[i] - s.y[i];
-    __syncthreads();
-    for (int j = tid; j < NP; j += BT)
-      s.b[j] = j < n ? (sigma * s.x[j] - s.q[j]) + a_col_dot(p, s.Av, s.w, j) : 0.0;
-    __syncthreads();
-    tile_gemv<T>(a, s.b, s.xt);
-    for (int r = 0; r < st.refine; ++r) {   // xt += Kinv (b - K xt)
-      for (int i = tid; i < m; i += BT) s.w[i] = s.rho[i] * a_row_dot(p, s.Av, s.xt, i);
+  while (stage != 3) {
+    int flags = 0;
+    bool checked = false, adapt_due = false;
+    if (stage == 0) {
+      ++iter;
+      if (st.profile) pt0 = wall_clock64();
+      // rhs of the reduced system: b = sigma x - q + A'(rho z - y)
+      for (int i = tid; i < m; i += BT) s_w[i] = s_rho[i] * s_z[i] - s_y[i];
       __syncthreads();
       for (int j = tid; j < NP; j += BT)
-        s.tn[j] = j < n ? s.b[j] - (p_row_dot(p, s.Pv, s.xt, j) + sigma * s.xt[j] + a_col_dot(p, s.Av, s.w, j)) : 0.0;
+        s_b[j] = j < n ? (sigma * s_x[j] - s_q[j]) + a_col_dot(s, s_w, j) : 0.0;
       __syncthreads();
-      tile_gemv<T>(a, s.tn, s.dx);          // dx is free until the x update below
-      for (int j = tid; j < n; j += BT) s.xt[j] += s.dx[j];
-      __syncthreads();
-    }
-    // z~ = A x~ ; x, z, y updates (auxil.c:185-225, proj.c:4-14)
-    for (int i = tid; i < m; i += BT) {
-      const double zt = a_row_dot(p, s.Av, s.xt, i);
-      const double zo = s.z[i], yo = s.y[i];
-      double v = alpha * zt + oma * zo + s.rinv[i] * yo;
-      v = fmax(v, s.l[i]);
-      const double zn = fmin(v, s.u[i]);
-      const double dy = s.rho[i] * (alpha * zt + oma * zo - zn);
-      s.z[i] = zn; s.dy[i] = dy; s.y[i] = yo + dy;
-    }
-    for (int j = tid; j < n; j += BT) {
-      const double xo = s.x[j];
-      const double xn = alpha * s.xt[j] + oma * xo;
-      s.dx[j] = xn - xo; s.x[j] = xn;
-    }
-    __syncthreads();
-
-    checked = st.check_termination && (iter % st.check_termination == 0);
-    bool fresh = false;
-    if (checked) { fresh = true; if (evaluate(false)) break; }
-    if (st.adaptive_rho && st.rho_interval && (iter % st.rho_interval == 0)) {
-      if (!fresh) { const int keep = status; evaluate(false); status = keep; }
-      const double rn = rho_estimate();
-      rho_est = rn;
-      if (rn > rho * st.adapt_tol || rn < rho / st.adapt_tol) {
-        rho = rn; rho_updates++;
+      PSTAMP(0);
+      tile_gemv<TR, TC>(a, s_b, s_xt);
+      PSTAMP(1);
+      for (int r = 0; r < st.refine; ++r) {   // xt += Kinv (b - K xt)
+        for (int i = tid; i < m; i += BT) s_w[i] = s_rho[i] * a_row_dot(s, s_xt, i);
         __syncthreads();
-        for (int i = tid; i < m; i += BT) {
-          const int t = s.ctype[i];
-          if (t == 0) { s.rho[i] = rho; s.rinv[i] = 1.0 / rho; }
-          else if (t == 1) { s.rho[i] = 1e3 * rho; s.rinv[i] = 1.0 / s.rho[i]; }
-        }
+        for (int j = tid; j < NP; j += BT)
+          s_tn[j] = j < n ? s_b[j] - (p_row_dot(s, s_xt, j) + sigma * s_xt[j] + a_col_dot(s, s_w, j)) : 0.0;
         __syncthreads();
-        form_K<T>(a, p, s, sigma);
-        invert_tiles<T>(a, s);
+        tile_gemv<TR, TC>(a, s_tn, s_dx);        // dx is free until the x update below
+        for (int j = tid; j < n; j += BT) s_xt[j] += s_dx[j];
+        __syncthreads();
       }
+      PSTAMP(2);
+      // z~ = A x~ ; x, z, y updates (auxil.c:185-225, proj.c:4-14)
+      for (int i = tid; i < m; i += BT) {
+        const double zt = a_row_dot(s, s_xt, i);
+        const double zo = s_z[i], yo = s_y[i];
+        double v = alpha * zt + oma * zo + s_rinv[i] * yo;
+        v = fmax(v, s_l[i]);
+        const double zn = fmin(v, s_u[i]);
+        const double dy = s_rho[i] * (alpha * zt + oma * zo - zn);
+        s_z[i] = zn; s_dy[i] = dy; s_y[i] = yo + dy;
+      }
+      for (int j = tid; j < n; j += BT) {
+        const double xo = s_x[j];
+        const double xn = alpha * s_xt[j] + oma * xo;
+        s_dx[j] = xn - xo; s_x[j] = xn;
+      }
+      __syncthreads();
+      PSTAMP(3);
+      norms_fresh = false;
+      checked = st.check_termination && (iter % st.check_termination == 0);
+      adapt_due = st.adaptive_rho && st.rho_interval && (iter % st.rho_interval == 0);
+      if (checked) flags = F_NORMS | F_STATUS;
+      else if (adapt_due) flags = F_NORMS;
+    } else if (stage == 1) flags = F_STATUS | (norms_fresh ? 0 : F_NORMS);
+    else flags = F_STATUS | F_APPROX;
+
+    bool term = false;
+    if (flags & F_NORMS) {
+      // ---- update_info: residuals and norms (auxil.c:227-318) ----
+      double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
+      for (int i = tid; i < m; i += BT) {
+        const double ax = a_row_dot(s, s_x, i);
+        const double pr = ax + (-1.0) * s_z[i];
+        const double ei = unscaled ? 1.0 / s_E[i] : 1.0;
+        m0 = fmax(m0, fabs(ei * pr)); m1 = fmax(m1, fabs(pr));
+        m2 = fmax(m2, fabs(ei * s_z[i])); m3 = fmax(m3, fabs(s_z[i]));
+        m4 = fmax(m4, fabs(ei * ax)); m5 = fmax(m5, fabs(ax));
+      }
+      m0 = b_max(m0, s.red); m1 = b_max(m1, s.red); m2 = b_max(m2, s.red);
+      m3 = b_max(m3, s.red); m4 = b_max(m4, s.red); m5 = b_max(m5, s.red);
+      if (tid == 0) {
+        sc[S_PRI] = m == 0 ? 0.0 : (unscaled ? m0 : m1);
+        sc[S_NPRI_S] = m1; sc[S_NZ] = unscaled ? m2 : m3; sc[S_NZ_S] = m3;
+        sc[S_NAX] = unscaled ? m4 : m5; sc[S_NAX_S] = m5;
+      }
+      double d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, d6 = 0, d7 = 0, ob = 0;
+      for (int j = tid; j < n; j += BT) {
+        const double px = p_row_dot(s, s_x, j);
+        const double aty = a_col_dot(s, s_y, j);
+        double dr = s_q[j] + px;
+        if (m > 0) dr = dr + aty;
+        const double di = unscaled ? 1.0 / s_D[j] : 1.0;
+        d0 = fmax(d0, fabs(di * dr)); d1 = fmax(d1, fabs(dr));
+        d2 = fmax(d2, fabs(di * s_q[j])); d3 = fmax(d3, fabs(s_q[j]));
+        d4 = fmax(d4, fabs(di * aty)); d5 = fmax(d5, fabs(aty));
+        d6 = fmax(d6, fabs(di * px)); d7 = fmax(d7, fabs(px));
+        ob += s_x[j] * (0.5 * px + s_q[j]);
+      }
+      d0 = b_max(d0, s.red); d1 = b_max(d1, s.red); d2 = b_max(d2, s.red); d3 = b_max(d3, s.red);
+      d4 = b_max(d4, s.red); d5 = b_max(d5, s.red); d6 = b_max(d6, s.red); d7 = b_max(d7, s.red);
+      ob = b_sum(ob, s.red);
+      if (tid == 0) {
+        const double f = unscaled ? cinv : 1.0;
+        sc[S_DUA] = unscaled ? d0 * cinv : d1; sc[S_NDUA_S] = d1;
+        sc[S_NQ] = (unscaled ? d2 : d3) * f; sc[S_NQ_S] = d3;
+        sc[S_NATY] = (unscaled ? d4 : d5) * f; sc[S_NATY_S] = d5;
+        sc[S_NPX] = (unscaled ? d6 : d7) * f; sc[S_NPX_S] = d7;
+        sc[S_OBJ] = ob * (st.scaling ? cinv : 1.0);
+      }
+      __syncthreads();
+      norms_fresh = true;
+    }
+    if (flags & F_STATUS) {
+      // ---- check_termination (auxil.c:681-786) ----
+      const bool approximate = flags & F_APPROX;
+      const double pri_res = sc[S_PRI], dua_res = sc[S_DUA];
+      int newstatus = 0;      // 0 = keep going
+      double newobj = 0.0;
+      if (pri_res > 1e30 || dua_res > 1e30) { newstatus = OSQP_NON_CVX; newobj = OSQP_NAN; }
+      else {
+        double ea = st.eps_abs, er = st.eps_rel, epi = st.eps_pinf, edi = st.eps_dinf;
+        if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+        bool prim_ok = false, dual_ok = false, pinf = false, dinf = false;
+        if (m == 0) prim_ok = true;
+        else if (pri_res < ea + er * fmax(sc[S_NZ], sc[S_NAX])) prim_ok = true;
+        else {
+          // is_primal_infeasible (auxil.c:361-424); projected dy kept in w
+          double nd = 0, lhs = 0;
+          for (int i = tid; i < m; i += BT) {
+            double dy = s_dy[i];
+            if (s_u[i] > BINF) { if (s_l[i] < -BINF) dy = 0.0; else dy = fmin(dy, 0.0); }
+            else if (s_l[i] < -BINF) dy = fmax(dy, 0.0);
+            s_w[i] = dy;
+            nd = fmax(nd, fabs(unscaled ? s_E[i] * dy : dy));
+            lhs += s_u[i] * fmax(dy, 0.0) + s_l[i] * fmin(dy, 0.0);
+          }
+          nd = b_max(nd, s.red); lhs = b_sum(lhs, s.red);
+          if (nd > 1e-30 && lhs < epi * nd) {
+            double mx = 0;
+            for (int j = tid; j < n; j += BT) {
+              double v = a_col_dot(s, s_w, j);
+              if (unscaled) v = v / s_D[j];
+              mx = fmax(mx, fabs(v));
+            }
+            mx = b_max(mx, s.red);
+            pinf = mx < epi * nd;
+          }
+        }
+        if (dua_res < ea + er * fmax(fmax(sc[S_NQ], sc[S_NATY]), sc[S_NPX])) dual_ok = true;
+        else {
+          // is_dual_infeasible (auxil.c:426-512)
+          double ndx = 0, qdx = 0;
+          for (int j = tid; j < n; j += BT) {
+            ndx = fmax(ndx, fabs(unscaled ? s_D[j] * s_dx[j] : s_dx[j]));
+            qdx += s_q[j] * s_dx[j];
+          }
+          ndx = b_max(ndx, s.red); qdx = b_sum(qdx, s.red);
+          const double csc_ = unscaled ? cs : 1.0;
+          if (ndx > 1e-30 && qdx < csc_ * edi * ndx) {
+            double mx = 0;
+            for (int j = tid; j < n; j += BT) {
+              double v = p_row_dot(s, s_dx, j);
+              if (unscaled) v = v / s_D[j];
+              mx = fmax(mx, fabs(v));
+            }
+            mx = b_max(mx, s.red);
+            if (mx < csc_ * edi * ndx) {
+              double viol = 0;
+              for (int i = tid; i < m; i += BT) {
+                double v = a_row_dot(s, s_dx, i);
+                if (unscaled) v = v / s_E[i];
+                if ((s_u[i] < BINF && v > edi * ndx) || (s_l[i] > -BINF && v < -edi * ndx)) viol += 1.0;
+              }
+              viol = b_sum(viol, s.red);
+              dinf = viol == 0.0;
+            }
+          }
+        }
+        if (prim_ok && dual_ok) newstatus = approximate ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED;
+        else if (pinf) { newstatus = approximate ? OSQP_PRIMAL_INFEASIBLE_INACCURATE : OSQP_PRIMAL_INFEASIBLE; newobj = OSQP_INFTY; }
+        else if (dinf) { newstatus = approximate ? OSQP_DUAL_INFEASIBLE_INACCURATE : OSQP_DUAL_INFEASIBLE; newobj = -OSQP_INFTY; }
+      }
+      __syncthreads();
+      if (newstatus != 0) {
+        term = true;
+        if (tid == 0) { sc[S_STATUS] = newstatus; if (newstatus != OSQP_SOLVED && newstatus != OSQP_SOLVED_INACCURATE) sc[S_OBJ] = newobj; }
+      }
+      __syncthreads();
+    }
+
+    if (stage == 0) {
+      if (checked && term) { stage = 3; continue; }
+      if (adapt_due) {     // adapt_rho (auxil.c:13-74)
+        const double pr = (m ? sc[S_NPRI_S] : 0.0) / (fmax(sc[S_NZ_S], sc[S_NAX_S]) + 1e-30);
+        const double du = sc[S_NDUA_S] / (fmax(fmax(sc[S_NQ_S], sc[S_NATY_S]), sc[S_NPX_S]) + 1e-30);
+        const double rn = fmin(fmax(rho * sqrt(pr / du), 1e-6), 1e6);
+        if (rn > rho * st.adapt_tol || rn < rho / st.adapt_tol) {
+          rho = rn; rho_updates++;
+          for (int i = tid; i < m; i += BT) {
+            const int t = s.ctype[i];
+            if (t == 0) { s_rho[i] = rho; s_rinv[i] = 1.0 / rho; }
+            else if (t == 1) { s_rho[i] = 1e3 * rho; s_rinv[i] = 1.0 / s_rho[i]; }
+          }
+          __syncthreads();
+          form_K<TR, TC>(a, n, s, sigma);
+          invert_tiles<TR, TC>(a, s);
+        }
+      }
+      if (iter >= st.max_iter) stage = checked ? 2 : 1;
+    } else if (stage == 1) stage = term ? 3 : 2;
+    else {
+      if (!term && tid == 0) sc[S_STATUS] = OSQP_MAX_ITER_REACHED;
+      __syncthreads();
+      stage = 3;
     }
   }
-  if (iter > st.max_iter) iter = st.max_iter;
-  if (!checked) evaluate(false);
-  if (status == OSQP_UNSOLVED) { if (!evaluate(true)) status = OSQP_MAX_ITER_REACHED; }
-  rho_est = rho_estimate();
+  tstamp[6] = wall_clock64();
+  const int status = (int)sc[S_STATUS];
+  const double pri_res = sc[S_PRI], dua_res = sc[S_DUA], obj = sc[S_OBJ];
+  double rho_est;
+  {
+    const double pr = (m ? sc[S_NPRI_S] : 0.0) / (fmax(sc[S_NZ_S], sc[S_NAX_S]) + 1e-30);
+    const double du = sc[S_NDUA_S] / (fmax(fmax(sc[S_NQ_S], sc[S_NATY_S]), sc[S_NPX_S]) + 1e-30);
+    rho_est = fmin(fmax(rho * sqrt(pr / du), 1e-6), 1e6);
+  }
 
   // ---- store_solution (auxil.c:524-562) ---------------------------------------
   const bool has_sol = !(status == OSQP_PRIMAL_INFEASIBLE || status == OSQP_PRIMAL_INFEASIBLE_INACCURATE ||
@@ -518,28 +624,33 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
   __syncthreads();
   if (has_sol) {
     for (int j = tid; j < n; j += BT) {
-      io.Xo[qp * n + j] = st.scaling ? s.x[j] * s.D[j] : s.x[j];
-      io.Xs[qp * n + j] = s.x[j];
+      io.Xo[qp * n + j] = st.scaling ? s_x[j] * s_D[j] : s_x[j];
+      io.Xs[qp * n + j] = s_x[j];
     }
     for (int i = tid; i < m; i += BT) {
-      io.Yo[qp * m + i] = st.scaling ? (s.y[i] * s.E[i]) * cinv : s.y[i];
-      io.Ys[qp * m + i] = s.y[i]; io.Zs[qp * m + i] = s.z[i];
+      io.Yo[qp * m + i] = st.scaling ? (s_y[i] * s_E[i]) * cinv : s_y[i];
+      io.Ys[qp * m + i] = s_y[i]; io.Zs[qp * m + i] = s_z[i];
     }
   } else {
     for (int j = tid; j < n; j += BT) { io.Xo[qp * n + j] = OSQP_NAN; io.Xs[qp * n + j] = 0.0; }
     for (int i = tid; i < m; i += BT) { io.Yo[qp * m + i] = OSQP_NAN; io.Ys[qp * m + i] = 0.0; io.Zs[qp * m + i] = 0.0; }
     if (status == OSQP_PRIMAL_INFEASIBLE || status == OSQP_PRIMAL_INFEASIBLE_INACCURATE) {
       double mx = 0;
-      for (int i = tid; i < m; i += BT) { s.w[i] = unscaled ? s.w[i] * s.E[i] : s.w[i]; mx = fmax(mx, fabs(s.w[i])); }
+      for (int i = tid; i < m; i += BT) { s_w[i] = unscaled ? s_w[i] * s_E[i] : s_w[i]; mx = fmax(mx, fabs(s_w[i])); }
       mx = b_max(mx, s.red);
-      for (int i = tid; i < m; i += BT) io.DYo[qp * m + i] = s.w[i] * (1.0 / mx);
+      for (int i = tid; i < m; i += BT) io.DYo[qp * m + i] = s_w[i] * (1.0 / mx);
     }
     if (status == OSQP_DUAL_INFEASIBLE || status == OSQP_DUAL_INFEASIBLE_INACCURATE) {
       double mx = 0;
-      for (int j = tid; j < n; j += BT) { s.tn[j] = unscaled ? s.dx[j] * s.D[j] : s.dx[j]; mx = fmax(mx, fabs(s.tn[j])); }
+      for (int j = tid; j < n; j += BT) { s_tn[j] = unscaled ? s_dx[j] * s_D[j] : s_dx[j]; mx = fmax(mx, fabs(s_tn[j])); }
       mx = b_max(mx, s.red);
-      for (int j = tid; j < n; j += BT) io.DXo[qp * n + j] = s.tn[j] * (1.0 / mx);
+      for (int j = tid; j < n; j += BT) io.DXo[qp * n + j] = s_tn[j] * (1.0 / mx);
     }
+  }
+  if (st.profile && tid == 0) {
+    tstamp[7] = wall_clock64();
+    for (int k = 0; k < 8; ++k) io.DXo[qp * n + k] = (double)(tstamp[k] - tstamp[0]);
+    for (int k = 0; k < 4; ++k) io.DXo[qp * n + 8 + k] = (double)pacc[k];
   }
   if (tid == 0) {
     double *inf = io.info + qp * 8;
@@ -598,6 +709,8 @@ static void fill_settings(osqp_amd_batch *b, const OSQPSettings *s) {
   t.scaled_termination = (int)s->scaled_termination; t.warm_start = (int)s->warm_start;
   const char *e = getenv("OSQP_AMD_BATCH_REFINE");
   t.refine = e ? atoi(e) : 1;
+  e = getenv("OSQP_AMD_BATCH_PROFILE");
+  t.profile = e ? atoi(e) : 0;   // phase time stamps (wall_clock64 ticks) written into DX[0..7]
 }
 
 extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const csc *P, const csc *A,
@@ -668,6 +781,12 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
   rc |= bupload(b, &pt.Fp, Fp); rc |= bupload(b, &pt.Fi, Fi); rc |= bupload(b, &pt.Fk, Fk);
   rc |= bupload(b, &pt.Ap, Ap); rc |= bupload(b, &pt.Ai, Ai); rc |= bupload(b, &pt.Ac, Ac);
   rc |= bupload(b, &pt.Rp, Rp); rc |= bupload(b, &pt.Rj, Rj); rc |= bupload(b, &pt.Rk, Rk);
+  {
+    std::vector<int> pk;
+    for (const std::vector<int> *v : {&Pp, &Pi, &Pc, &Fp, &Fi, &Fk, &Ap, &Ai, &Ac, &Rp, &Rj, &Rk})
+      pk.insert(pk.end(), v->begin(), v->end());
+    rc |= bupload(b, &pt.packed, pk);
+  }
 
   // ---- values and per-QP arrays ----------------------------------------------
   BIO &io = b->io;
@@ -693,8 +812,9 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
   if (rc || hipStreamSynchronize(b->stream) != hipSuccess) { osqp_amd_batch_cleanup(b); return OSQP_LINSYS_SOLVER_INIT_ERROR; }
 
   const int NP = 16 * b->tile;
-  b->lds_bytes = sizeof(double) * ((size_t)b->nnzP + b->nnzA + 7 * NP + 11 * (size_t)m + 4 * NP + 8) +
-                 sizeof(int) * (size_t)(m + 4);
+  b->lds_bytes = sizeof(double) * ((size_t)b->nnzP + b->nnzA + 7 * NP + 11 * (size_t)m + 4 * NP + 32) +
+                 sizeof(int) * ((size_t)m + 4 + 3 * ((size_t)n + 1) + 2 * (size_t)b->nnzP + 2 * (size_t)Fp[n] +
+                                4 * (size_t)b->nnzA + (size_t)m + 1);
   b->lds_bytes = (b->lds_bytes + 15) & ~(size_t)15;
   if (b->lds_bytes > 160 * 1024) {
     fprintf(stderr, "osqp_amd batch: problem needs %zu B of LDS per QP (> 160 KiB)\n", b->lds_bytes);
@@ -702,9 +822,9 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
     return OSQP_LINSYS_SOLVER_INIT_ERROR;
   }
   if (b->lds_bytes > 64 * 1024) {
-    if (b->tile == 8) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_solve<8>),
+    if (b->tile == 8) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_solve<8, 4>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes);
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_solve<4>),
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_solve<4, 2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes);
   }
   b->h_info.assign(B * 8, 0.0);
@@ -737,9 +857,9 @@ extern "C" c_int osqp_amd_batch_solve(osqp_amd_batch *b) {
   BCHK(hipSetDevice(b->device));
   const int first = b->solves == 0;
   if (b->tile == 8)
-    hipLaunchKernelGGL(k_batch_solve<8>, dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, first);
+    hipLaunchKernelGGL((k_batch_solve<8, 4>), dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, first);
   else
-    hipLaunchKernelGGL(k_batch_solve<4>, dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, first);
+    hipLaunchKernelGGL((k_batch_solve<4, 2>), dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, first);
   BCHK(hipGetLastError());
   BCHK(hipStreamSynchronize(b->stream));
   b->solves++;

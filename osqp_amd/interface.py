@@ -5,7 +5,7 @@ u, **settings)`, `.solve()`, `.update(...)`, `.warm_start(...)`,
 libosqp_amd.so (HIP); this file only marshals arrays.
 
 `SolverHandle` is library-agnostic (library + symbol prefix) so the tests can
-drive the CPU oracle through exactly the same Python code path.
+drive a second library with the same ABI through exactly the same Python code path.
 """
 import ctypes as C
 from types import SimpleNamespace

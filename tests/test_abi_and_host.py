@@ -1,0 +1,161 @@
+"""CPU tests of the product side that need no GPU: the C-ABI library loads and
+exports every symbol the headers in include/ declare; struct layouts match the
+C side; setup fails loudly (no CPU fallback) when no HIP device is present;
+the sharded batch path gathers correctly over gloo with world_size 2."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def _declared_functions(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", txt)
+    return sorted(set(n for n in names if not n.startswith("__") and n not in ("defined",)))
+
+
+@pytest.fixture(scope="module")
+def product_lib():
+    import osqp_amd
+    osqp_amd.build()
+    return osqp_amd.lib()
+
+
+@pytest.mark.parametrize("header", ["osqp_amd.h", "osqp_amd_engine.h", "osqp_amd_batch.h"])
+def test_library_exports_every_declared_symbol(product_lib, header):
+    names = _declared_functions(header)
+    assert len(names) >= 6
+    missing = [n for n in names if not hasattr(product_lib, n)]
+    assert not missing, missing
+
+
+def test_struct_sizes_match_c(product_lib, tmp_path):
+    """ctypes mirrors (osqp_amd/_abi.py) vs sizeof/offsetof compiled from the header."""
+    from osqp_amd import abi
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "osqp_amd_types.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(csc), sizeof(OSQPSettings),'
+                   'sizeof(OSQPInfo), sizeof(OSQPData), sizeof(OSQPWorkspace), sizeof(struct linsys_solver),'
+                   'offsetof(OSQPSettings, linsys_solver), offsetof(OSQPInfo, obj_val));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(t) for t in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(abi.csc), C.sizeof(abi.OSQPSettings), C.sizeof(abi.OSQPInfo), C.sizeof(abi.OSQPData),
+            C.sizeof(abi.OSQPWorkspace), C.sizeof(abi.LinSysSolver), abi.OSQPSettings.linsys_solver.offset,
+            abi.OSQPInfo.obj_val.offset]
+    assert got == want
+
+
+def test_default_settings_match_reference_constants(product_lib):
+    """include/constants.h:58-118 defaults (linsys_solver defaults to the HIP PCG id)."""
+    import osqp_amd
+    from osqp_amd import abi
+    st = abi.OSQPSettings()
+    product_lib.osqp_set_default_settings.restype = None
+    product_lib.osqp_set_default_settings.argtypes = [C.POINTER(abi.OSQPSettings)]
+    product_lib.osqp_set_default_settings(C.byref(st))
+    assert (st.rho, st.sigma, st.scaling, st.max_iter) == (0.1, 1e-6, 10, 4000)
+    assert (st.eps_abs, st.eps_rel, st.eps_prim_inf, st.eps_dual_inf, st.alpha) == (1e-3, 1e-3, 1e-4, 1e-4, 1.6)
+    assert (st.adaptive_rho, st.adaptive_rho_interval, st.adaptive_rho_tolerance, st.adaptive_rho_fraction) == (1, 0, 5.0, 0.4)
+    assert (st.check_termination, st.warm_start, st.polish, st.polish_refine_iter, st.delta) == (25, 1, 0, 3, 1e-6)
+    assert st.linsys_solver == abi.HIP_PCG_SOLVER
+
+
+def test_validation_happens_before_any_device_work(product_lib):
+    """Invalid data / settings are rejected with the reference's codes 1 / 2 on a CPU-only box."""
+    import osqp_amd
+    pb, _ = load_golden("basic_qp")
+    with pytest.raises(ValueError, match="error 2"):
+        osqp_amd.OSQP().setup(**pb, rho=-1.0)
+    bad = dict(pb); bad["l"] = pb["u"] + 1.0; bad["l"][3] = 0.0
+    with pytest.raises(ValueError, match="error 1"):
+        osqp_amd.OSQP().setup(**bad)
+
+
+def test_no_cpu_fallback_without_gpu(product_lib):
+    """Without a HIP device the product refuses to set up (OSQP_LINSYS_SOLVER_LOAD_ERROR = 3)
+    instead of silently computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import osqp_amd
+    pb, _ = load_golden("basic_qp")
+    with pytest.raises(ValueError, match="error 3"):
+        osqp_amd.OSQP().setup(**pb)
+    from osqp_amd.problems import mpc_batch
+    s, Q, L, U = mpc_batch(2)
+    with pytest.raises(ValueError, match="error 3"):
+        osqp_amd.BatchOSQP().setup(s["P"], s["A"], Q, L, U)
+
+
+def test_product_sources_do_not_reference_the_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "osqp_amd")):
+        for f in fs:
+            if f.endswith((".py", ".c", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"\boracle\b|\borc_", txt):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    for h in os.listdir(os.path.join(ROOT, "include")):
+        assert "orc_" not in open(os.path.join(ROOT, "include", h)).read()
+
+
+def test_shard_ranges_cover_the_batch():
+    from osqp_amd.dist import shard_range
+    for B in (1, 7, 1024, 1025):
+        for W in (1, 2, 3, 8):
+            got = []
+            for r in range(W):
+                lo, hi, per = shard_range(B, r, W)
+                got += list(range(lo, hi))
+                assert hi - lo <= per
+            assert got == list(range(B))
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from osqp_amd.dist import sharded_batch_solve
+from osqp_amd.problems import mpc_batch
+import oracle.oracle as orc
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+s, Q, L, U = mpc_batch(6)
+def local(Qs, Ls, Us):      # CPU stand-in for the per-rank GPU batch solve (test only)
+    X = np.zeros((len(Qs), s["n"])); Y = np.zeros((len(Qs), s["m"])); I = np.zeros((len(Qs), 8))
+    for b in range(len(Qs)):
+        r = orc.OracleOSQP().setup(P=s["P"], q=Qs[b], A=s["A"], l=Ls[b], u=Us[b]).solve()
+        X[b], Y[b] = r.x, r.y; I[b, 0], I[b, 1], I[b, 2] = r.info.iter, r.info.status_val, r.info.obj_val
+    return X, Y, I
+X, Y, I = sharded_batch_solve(local, Q, L, U)
+np.save(os.path.join(%(out)r, "rank%%d.npy" %% dist.get_rank()), np.concatenate([X, Y, I], axis=1))
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_batch_gather_gloo_world2(tmp_path, oracle_mod):
+    """N > 1 path on CPU: two gloo ranks each solve their contiguous shard and one
+    all_gather returns the whole batch, identical on both ranks and equal to a
+    single-process run."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % dict(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    a = np.load(tmp_path / "rank0.npy"); b = np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(a, b) and a.shape[0] == 6
+    from osqp_amd.problems import mpc_batch
+    s, Q, L, U = mpc_batch(6)
+    for i in range(6):
+        r = oracle_mod.OracleOSQP().setup(P=s["P"], q=Q[i], A=s["A"], l=L[i], u=U[i]).solve()
+        assert np.array_equal(a[i, :s["n"]], r.x) and a[i, s["n"] + s["m"]] == r.info.iter
