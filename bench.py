@@ -140,8 +140,8 @@ def bench_batch(batch, dist, rank, local_rank, world, steps=10, with_cpu=True):
                n=s["n"], m=s["m"], ms_per_batch=round(1e3 * dt, 4), solved=int((status == 1).sum()),
                mean_iters=round(float(iters.mean()), 2), max_iters=int(iters.max()),
                gather_ms=round(gather_ms, 3),
-               note="one workgroup per QP; setup (Ruiz scaling, K^-1) is inside the timed kernel; "
-                    "q,l,u resident in HBM, results left in HBM")
+               note="one 512-thread workgroup per QP; cold-started solves (warm_start=0) on the set-up batch "
+                    "(scaled data + K^-1 resident in HBM, like the reference's workspace); results left in HBM")
     if with_cpu and rank == 0 and world == 1:
         import oracle.oracle as orc
         orc.build()

@@ -66,6 +66,14 @@ struct BIO {               // per-batch arrays (device)
   double *Xo, *Yo;         // unscaled solution out
   double *DXo, *DYo;       // certificates out
   double *rho_io;          // current rho per QP (persists between solves)
+  // per-QP workspace written by the setup phase (the analogue of the reference's
+  // scaled OSQPData + factorisation, kept across solves like its workspace)
+  double *Wv;              // [B][nnzP + nnzA] scaled matrix values
+  double *Wq, *Wl, *Wu;    // scaled q, l, u
+  double *Wd, *We, *Wc;    // D [B][n], E [B][m], c [B]
+  double *Wk;              // [B][NP*NP] K^-1 in per-thread tile order
+  int    *Wt;              // [B][m] constraint class
+  int    *flag;            // [B] 1 = K^-1 must be rebuilt (constraint class changed)
   double *info;            // [B][8]: iter, status, obj, pri, dua, rho_updates, rho_estimate, rho
 };
 
@@ -108,6 +116,7 @@ struct BL {
   double *Pv, *Av;          // scaled matrix values (triu P, CSC A)
   double *nv, *mv;          // n-vector block (stride NP), m-vector block (stride m)
   double *rowk, *colk;      // Gauss-Jordan exchange (2 x 2 x NP)
+  double *gp;               // GEMV partial sums (32 x NP)
   double *red;
   int *ctype;
   int NP, m;
@@ -196,7 +205,7 @@ __device__ __forceinline__ void form_K(double (&a)[TR][TC], int n, const BL &s, 
 // In-place Gauss-Jordan inversion without pivoting (K is SPD).  One barrier per
 // pivot: the pivot row / column are exchanged through double-buffered LDS.
 template <int TR, int TC>
-__device__ __forceinline__ void invert_tiles(double (&a)[TR][TC], const BL &s) {
+__device__ __forceinline__ void invert_tiles(double (&a)[TR][TC], const BL &s, int n) {
   // The pivot loop is unrolled by TR (a multiple of TC) so that the pivot's
   // position inside a tile (ko, kco) is a compile-time constant: the register
   // tile is only ever indexed statically.  Per pivot: owners publish row k and
@@ -205,33 +214,33 @@ __device__ __forceinline__ void invert_tiles(double (&a)[TR][TC], const BL &s) {
   static_assert(TR % TC == 0, "tile shape");
   constexpr int NP = 16 * TR;
   const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
+  const int nkb = (n + TR - 1) / TR;    // padded rows/columns are identity: nothing to eliminate
 #pragma unroll 1
-  for (int kb = 0; kb < 16; ++kb) {
+  for (int kb = 0; kb < nkb; ++kb) {
 #pragma unroll
     for (int ko = 0; ko < TR; ++ko) {
-      constexpr int dummy = 0; (void)dummy;
       const int k = kb * TR + ko;
       const int kco = ko % TC;               // static after unrolling
       const int kc = k / TC;                 // column block that owns column k
       double *rowk = s.rowk + (k & 1) * NP, *colk = s.colk + (k & 1) * NP;
       if (tr == kb) {
 #pragma unroll
-        for (int c = 0; c < TC; ++c) rowk[tc * TC + c] = a[ko][c];
+        for (int c = 0; c < TC; ++c) rowk[c * 32 + tc] = a[ko][c];   // [c][tc]: lane stride 8 B
       }
       if (tc == kc) {
 #pragma unroll
         for (int r = 0; r < TR; ++r) colk[tr * TR + r] = a[r][kco];
       }
       __syncthreads();
-      const double piv = 1.0 / rowk[k];
+      const double piv = 1.0 / rowk[kco * 32 + kc];
       double rk[TC];
 #pragma unroll
-      for (int c = 0; c < TC; ++c) rk[c] = rowk[tc * TC + c] * piv;
+      for (int c = 0; c < TC; ++c) rk[c] = rowk[c * 32 + tc] * piv;
 #pragma unroll
       for (int r = 0; r < TR; ++r) {
         const double ci = colk[tr * TR + r];
 #pragma unroll
-        for (int c = 0; c < TC; ++c) a[r][c] = a[r][c] - ci * rk[c];
+        for (int c = 0; c < TC; ++c) a[r][c] = __builtin_fma(-ci, rk[c], a[r][c]);
       }
       if (tc == kc) {          // column k: a_ik <- -a_ik / a_kk
 #pragma unroll
@@ -248,30 +257,30 @@ __device__ __forceinline__ void invert_tiles(double (&a)[TR][TC], const BL &s) {
 
 // out_i = sum_j Kinv_ij in_j ; in / out are LDS vectors of length >= NP
 template <int TR, int TC>
-__device__ __forceinline__ void tile_gemv(const double (&a)[TR][TC], const double *in, double *out) {
+__device__ __forceinline__ void tile_gemv(const double (&a)[TR][TC], const double *in, double *out,
+                                          double *gp) {
+  // partial sums of each thread's tile go through LDS (gp: NP rows x 33 doubles,
+  // one padding word per row => conflict-free writes and reads) and are added in
+  // ascending column-block order by the first NP threads: fixed order, no
+  // cross-lane shuffles.
+  constexpr int NP = 16 * TR;
   const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
-  double bj[TC], acc[TR];
+  double bj[TC];
 #pragma unroll
   for (int c = 0; c < TC; ++c) bj[c] = in[tc * TC + c];
 #pragma unroll
   for (int r = 0; r < TR; ++r) {
     double v = 0.0;
 #pragma unroll
-    for (int c = 0; c < TC; ++c) v += a[r][c] * bj[c];
-    acc[r] = v;
+    for (int c = 0; c < TC; ++c) v = __builtin_fma(a[r][c], bj[c], v);
+    gp[(tr * TR + r) * 33 + tc] = v;
   }
-  // fixed xor tree over the 32 lanes that share a row block
-#pragma unroll
-  for (int r = 0; r < TR; ++r) {
-    double v = acc[r];
-    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64);  v += __shfl_xor(v, 1, 64);
-    acc[r] = v;
-  }
-  __syncthreads();            // readers of `out`'s previous contents are done
-  if (tc == 0) {
-#pragma unroll
-    for (int r = 0; r < TR; ++r) out[tr * TR + r] = acc[r];
+  __syncthreads();
+  if (threadIdx.x < NP) {
+    double v = 0.0;
+#pragma unroll 8
+    for (int t = 0; t < 32; ++t) v += gp[threadIdx.x * 33 + t];
+    out[threadIdx.x] = v;
   }
   __syncthreads();
 }
@@ -280,7 +289,7 @@ __device__ __forceinline__ void tile_gemv(const double (&a)[TR][TC], const doubl
 // the kernel
 // ---------------------------------------------------------------------------
 template <int TR, int TC>
-__global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BIO io, int first_solve) {
+__global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BIO io, int phase) {
   constexpr int NP = 16 * TR;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int n = p.n, m = p.m, tid = threadIdx.x;
@@ -291,7 +300,7 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
     s.NP = NP; s.m = m;
     s.Pv = w; w += p.nnzP; s.Av = w; w += p.nnzA;
     s.nv = w; w += 7 * NP; s.mv = w; w += 11 * m;
-    s.rowk = w; w += 2 * NP; s.colk = w; w += 2 * NP; s.red = w; w += 32;
+    s.rowk = w; w += 2 * NP; s.colk = w; w += 2 * NP; s.red = w; w += 32; s.gp = w; w += 33 * NP;
     int *iw = reinterpret_cast<int *>(w);
     s.ctype = iw; iw += m;
     int *ib = iw;
@@ -306,25 +315,38 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
   double a[TR][TC];
   unsigned long long tstamp[8];
   tstamp[0] = wall_clock64();
+  const unsigned long long cyc0 = clock64();
 
-  // ---- load the problem -----------------------------------------------------
-  const double *Pg = io.Px + qp * io.strideP, *Ag = io.Ax + qp * io.strideA;
-  for (int k = tid; k < p.nnzP; k += BT) s.Pv[k] = Pg[k];
-  for (int k = tid; k < p.nnzA; k += BT) s.Av[k] = Ag[k];
+  // ---- load: raw problem (setup phase) or the per-QP workspace (solve phase) ---
+  double cs = 1.0;   // cost scaling c
   for (int j = tid; j < NP; j += BT) {
-    s_q[j] = j < n ? io.Q[qp * n + j] : 0.0;
-    s_x[j] = 0.0; s_xt[j] = 0.0; s_dx[j] = 0.0; s_D[j] = 1.0; s_tn[j] = 0.0; s_b[j] = 0.0;
+    s_q[j] = 0.0; s_x[j] = 0.0; s_xt[j] = 0.0; s_dx[j] = 0.0; s_D[j] = 1.0; s_tn[j] = 0.0; s_b[j] = 0.0;
   }
-  for (int i = tid; i < m; i += BT) {
-    s_l[i] = io.L[qp * m + i]; s_u[i] = io.U[qp * m + i];
-    s_z[i] = 0.0; s_y[i] = 0.0; s_E[i] = 1.0; s_dy[i] = 0.0; s_zt[i] = 0.0;
+  for (int i = tid; i < m; i += BT) { s_z[i] = 0.0; s_y[i] = 0.0; s_E[i] = 1.0; s_dy[i] = 0.0; s_zt[i] = 0.0; }
+  __syncthreads();
+  const long long nv_ = (long long)p.nnzP + p.nnzA;
+  if (phase == 0) {
+    const double *Pg = io.Px + qp * io.strideP, *Ag = io.Ax + qp * io.strideA;
+    for (int k = tid; k < p.nnzP; k += BT) s.Pv[k] = Pg[k];
+    for (int k = tid; k < p.nnzA; k += BT) s.Av[k] = Ag[k];
+    for (int j = tid; j < n; j += BT) s_q[j] = io.Q[qp * n + j];
+    for (int i = tid; i < m; i += BT) { s_l[i] = io.L[qp * m + i]; s_u[i] = io.U[qp * m + i]; }
+  } else {
+    const double *Wv = io.Wv + qp * nv_;
+    for (int k = tid; k < p.nnzP; k += BT) s.Pv[k] = Wv[k];
+    for (int k = tid; k < p.nnzA; k += BT) s.Av[k] = Wv[p.nnzP + k];
+    for (int j = tid; j < n; j += BT) { s_q[j] = io.Wq[qp * n + j]; s_D[j] = io.Wd[qp * n + j]; }
+    for (int i = tid; i < m; i += BT) {
+      s_l[i] = io.Wl[qp * m + i]; s_u[i] = io.Wu[qp * m + i]; s_E[i] = io.We[qp * m + i];
+      s.ctype[i] = io.Wt[qp * m + i];
+    }
+    cs = io.Wc[qp];
   }
   __syncthreads();
 
   tstamp[1] = wall_clock64();
   // ---- Ruiz equilibration (scaling.c:44-156), per QP -------------------------
-  double cs = 1.0;   // cost scaling c
-  for (int pass = 0; pass < st.scaling; ++pass) {
+  for (int pass = 0; phase == 0 && pass < st.scaling; ++pass) {
     for (int j = tid; j < n; j += BT) {
       double v = 0.0;
       for (int k = s.Fp[j]; k < s.Fp[j + 1]; ++k) v = fmax(v, fabs(s.Pv[s.Fk[k]]));
@@ -363,31 +385,61 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
   }
   const double cinv = 1.0 / cs;
   const bool unscaled = st.scaling && !st.scaled_termination;
-  for (int i = tid; i < m; i += BT) { s_l[i] = s_l[i] * s_E[i]; s_u[i] = s_u[i] * s_E[i]; }
+  if (phase == 0) { for (int i = tid; i < m; i += BT) { s_l[i] = s_l[i] * s_E[i]; s_u[i] = s_u[i] * s_E[i]; } }
   __syncthreads();
 
   tstamp[2] = wall_clock64();
   // ---- rho vector (auxil.c:76-98) and warm start -----------------------------
-  double rho = (first_solve || !io.rho_io) ? st.rho : io.rho_io[qp];
+  double rho = phase == 0 ? st.rho : io.rho_io[qp];
   rho = fmin(fmax(rho, 1e-6), 1e6);
   for (int i = tid; i < m; i += BT) {
     int t = 0;
-    if (s_l[i] < -BINF && s_u[i] > BINF) t = -1;
-    else if (s_u[i] - s_l[i] < st.rho_tol) t = 1;
-    s.ctype[i] = t;
+    if (phase == 0) {
+      if (s_l[i] < -BINF && s_u[i] > BINF) t = -1;
+      else if (s_u[i] - s_l[i] < st.rho_tol) t = 1;
+      s.ctype[i] = t;
+    } else t = s.ctype[i];
     const double r = t == -1 ? 1e-6 : (t == 1 ? 1e3 * rho : rho);
     s_rho[i] = r; s_rinv[i] = 1.0 / r;
   }
-  if (st.warm_start && !first_solve) {
+  if (st.warm_start && phase != 0) {
     for (int j = tid; j < n; j += BT) s_x[j] = io.Xs[qp * n + j];
     for (int i = tid; i < m; i += BT) { s_z[i] = io.Zs[qp * m + i]; s_y[i] = io.Ys[qp * m + i]; }
   }
   __syncthreads();
   tstamp[3] = wall_clock64();
-  form_K<TR, TC>(a, n, s, st.sigma);
-  tstamp[4] = wall_clock64();
-  invert_tiles<TR, TC>(a, s);
+  bool kinv_dirty = false;
+  double *Wk = io.Wk + qp * (long long)(NP * NP);
+  if (phase == 0 || io.flag[qp]) {
+    form_K<TR, TC>(a, n, s, st.sigma);
+    tstamp[4] = wall_clock64();
+    invert_tiles<TR, TC>(a, s, n);
+    kinv_dirty = true;
+  } else {
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) a[r][c] = Wk[(r * TC + c) * BT + tid];
+    tstamp[4] = wall_clock64();
+  }
   tstamp[5] = wall_clock64();
+  if (phase == 0) {
+    // ---- store the workspace and stop: the solve phase starts from here -------
+    double *Wv = io.Wv + qp * nv_;
+    for (int k = tid; k < p.nnzP; k += BT) Wv[k] = s.Pv[k];
+    for (int k = tid; k < p.nnzA; k += BT) Wv[p.nnzP + k] = s.Av[k];
+    for (int j = tid; j < n; j += BT) { io.Wq[qp * n + j] = s_q[j]; io.Wd[qp * n + j] = s_D[j]; io.Xs[qp * n + j] = 0.0; }
+    for (int i = tid; i < m; i += BT) {
+      io.Wl[qp * m + i] = s_l[i]; io.Wu[qp * m + i] = s_u[i]; io.We[qp * m + i] = s_E[i];
+      io.Wt[qp * m + i] = s.ctype[i]; io.Zs[qp * m + i] = 0.0; io.Ys[qp * m + i] = 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) Wk[(r * TC + c) * BT + tid] = a[r][c];
+    if (tid == 0) { io.Wc[qp] = cs; io.rho_io[qp] = rho; io.flag[qp] = 0; }
+    return;
+  }
 
   // ---- ADMM loop (osqp.c:354-532) ---------------------------------------------
   // Uniform scalars (norms, residuals, status) live in LDS (`sc`), not in
@@ -419,7 +471,7 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
         s_b[j] = j < n ? (sigma * s_x[j] - s_q[j]) + a_col_dot(s, s_w, j) : 0.0;
       __syncthreads();
       PSTAMP(0);
-      tile_gemv<TR, TC>(a, s_b, s_xt);
+      tile_gemv<TR, TC>(a, s_b, s_xt, s.gp);
       PSTAMP(1);
       for (int r = 0; r < st.refine; ++r) {   // xt += Kinv (b - K xt)
         for (int i = tid; i < m; i += BT) s_w[i] = s_rho[i] * a_row_dot(s, s_xt, i);
@@ -427,7 +479,7 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
         for (int j = tid; j < NP; j += BT)
           s_tn[j] = j < n ? s_b[j] - (p_row_dot(s, s_xt, j) + sigma * s_xt[j] + a_col_dot(s, s_w, j)) : 0.0;
         __syncthreads();
-        tile_gemv<TR, TC>(a, s_tn, s_dx);        // dx is free until the x update below
+        tile_gemv<TR, TC>(a, s_tn, s_dx, s.gp);        // dx is free until the x update below
         for (int j = tid; j < n; j += BT) s_xt[j] += s_dx[j];
         __syncthreads();
       }
@@ -596,7 +648,8 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
           }
           __syncthreads();
           form_K<TR, TC>(a, n, s, sigma);
-          invert_tiles<TR, TC>(a, s);
+          invert_tiles<TR, TC>(a, s, n);
+          kinv_dirty = true;
         }
       }
       if (iter >= st.max_iter) stage = checked ? 2 : 1;
@@ -651,13 +704,51 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
     tstamp[7] = wall_clock64();
     for (int k = 0; k < 8; ++k) io.DXo[qp * n + k] = (double)(tstamp[k] - tstamp[0]);
     for (int k = 0; k < 4; ++k) io.DXo[qp * n + 8 + k] = (double)pacc[k];
+    io.DXo[qp * n + 12] = (double)(clock64() - cyc0);
+  }
+  if (kinv_dirty) {
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) Wk[(r * TC + c) * BT + tid] = a[r][c];
   }
   if (tid == 0) {
+    io.flag[qp] = 0;
     double *inf = io.info + qp * 8;
     inf[0] = iter; inf[1] = status; inf[2] = obj; inf[3] = pri_res; inf[4] = dua_res;
     inf[5] = rho_updates; inf[6] = rho_est; inf[7] = rho;
     if (io.rho_io) io.rho_io[qp] = rho;
   }
+}
+
+// osqp_update_lin_cost / osqp_update_bounds for every QP of the batch
+// (src/osqp.c:765-846): new raw vectors are scaled with the stored D, E, c; rows
+// are re-classified and a changed class requests a rebuild of K^-1
+// (update_rho_vec, src/auxil.c:100-142).
+__global__ void __launch_bounds__(256) k_batch_update(int n, int m, BIO io, const double *Q, const double *L,
+                                                      const double *U, double rho_tol) {
+  const long long qp = blockIdx.x;
+  __shared__ int changed;
+  if (threadIdx.x == 0) changed = 0;
+  __syncthreads();
+  if (Q) {
+    const double c = io.Wc[qp];
+    for (int j = threadIdx.x; j < n; j += blockDim.x) io.Wq[qp * n + j] = (Q[qp * n + j] * io.Wd[qp * n + j]) * c;
+  }
+  for (int i = threadIdx.x; i < m; i += blockDim.x) {
+    const double e = io.We[qp * m + i];
+    if (L) io.Wl[qp * m + i] = L[qp * m + i] * e;
+    if (U) io.Wu[qp * m + i] = U[qp * m + i] * e;
+    if (L || U) {
+      const double l = io.Wl[qp * m + i], u = io.Wu[qp * m + i];
+      int t = 0;
+      if (l < -BINF && u > BINF) t = -1;
+      else if (u - l < rho_tol) t = 1;
+      if (t != io.Wt[qp * m + i]) { io.Wt[qp * m + i] = t; changed = 1; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && changed) io.flag[qp] = 1;
 }
 
 // ---------------------------------------------------------------------------
@@ -675,6 +766,7 @@ struct osqp_amd_batch {
   size_t lds_bytes = 0;
   int solves = 0;
   std::vector<double> h_info;
+  double *dQ = nullptr, *dL = nullptr, *dU = nullptr;   // staging for updates
 };
 
 template <typename Tp>
@@ -800,6 +892,14 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
   rc |= balloc(b, &io.Xo, B * n); rc |= balloc(b, &io.Yo, B * m);
   rc |= balloc(b, &io.DXo, B * n); rc |= balloc(b, &io.DYo, B * m);
   rc |= balloc(b, &io.rho_io, B); rc |= balloc(b, &io.info, B * 8);
+  {
+    const size_t NPs = (size_t)16 * b->tile;
+    rc |= balloc(b, &io.Wv, B * ((size_t)b->nnzP + b->nnzA));
+    rc |= balloc(b, &io.Wq, B * n); rc |= balloc(b, &io.Wl, B * m); rc |= balloc(b, &io.Wu, B * m);
+    rc |= balloc(b, &io.Wd, B * n); rc |= balloc(b, &io.We, B * m); rc |= balloc(b, &io.Wc, B);
+    rc |= balloc(b, &io.Wk, B * NPs * NPs); rc |= balloc(b, &io.Wt, B * m); rc |= balloc(b, &io.flag, B);
+    rc |= balloc(b, &b->dQ, B * n); rc |= balloc(b, &b->dL, B * m); rc |= balloc(b, &b->dU, B * m);
+  }
   if (rc) { osqp_amd_batch_cleanup(b); return OSQP_MEM_ALLOC_ERROR; }
   io.Px = dPx; io.Ax = dAx; io.Q = dQ; io.L = dL; io.U = dU;
   auto up = [&](double *d, const c_float *s, size_t cnt) -> int {
@@ -812,7 +912,7 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
   if (rc || hipStreamSynchronize(b->stream) != hipSuccess) { osqp_amd_batch_cleanup(b); return OSQP_LINSYS_SOLVER_INIT_ERROR; }
 
   const int NP = 16 * b->tile;
-  b->lds_bytes = sizeof(double) * ((size_t)b->nnzP + b->nnzA + 7 * NP + 11 * (size_t)m + 4 * NP + 32) +
+  b->lds_bytes = sizeof(double) * ((size_t)b->nnzP + b->nnzA + 7 * NP + 11 * (size_t)m + 4 * NP + 32 + 33 * NP) +
                  sizeof(int) * ((size_t)m + 4 + 3 * ((size_t)n + 1) + 2 * (size_t)b->nnzP + 2 * (size_t)Fp[n] +
                                 4 * (size_t)b->nnzA + (size_t)m + 1);
   b->lds_bytes = (b->lds_bytes + 15) & ~(size_t)15;
@@ -828,6 +928,15 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes);
   }
   b->h_info.assign(B * 8, 0.0);
+  // setup phase on the device: Ruiz scaling, rho classes, K^-1 (one workgroup per QP)
+  if (b->tile == 8)
+    hipLaunchKernelGGL((k_batch_solve<8, 4>), dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, 0);
+  else
+    hipLaunchKernelGGL((k_batch_solve<4, 2>), dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, 0);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) {
+    osqp_amd_batch_cleanup(b);
+    return OSQP_LINSYS_SOLVER_INIT_ERROR;
+  }
   *out = b;
   return 0;
 }
@@ -845,9 +954,14 @@ extern "C" c_int osqp_amd_batch_update(osqp_amd_batch *b, const c_float *Q, cons
   if (!b) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   BCHK(hipSetDevice(b->device));
   const size_t B = (size_t)b->B;
-  if (Q) BCHK(hipMemcpyAsync(const_cast<double *>(b->io.Q), Q, B * b->n * sizeof(double), hipMemcpyHostToDevice, b->stream));
-  if (L) BCHK(hipMemcpyAsync(const_cast<double *>(b->io.L), L, B * b->m * sizeof(double), hipMemcpyHostToDevice, b->stream));
-  if (U) BCHK(hipMemcpyAsync(const_cast<double *>(b->io.U), U, B * b->m * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  if (L && U)
+    for (size_t k = 0; k < B * (size_t)b->m; k++) if (L[k] > U[k]) return 1;   // osqp.c:815-822
+  if (Q) BCHK(hipMemcpyAsync(b->dQ, Q, B * b->n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  if (L) BCHK(hipMemcpyAsync(b->dL, L, B * b->m * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  if (U) BCHK(hipMemcpyAsync(b->dU, U, B * b->m * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  hipLaunchKernelGGL(k_batch_update, dim3((unsigned)B), dim3(256), 0, b->stream, b->n, b->m, b->io,
+                     Q ? b->dQ : nullptr, L ? b->dL : nullptr, U ? b->dU : nullptr, (double)RHO_TOL);
+  BCHK(hipGetLastError());
   BCHK(hipStreamSynchronize(b->stream));
   return 0;
 }
@@ -855,11 +969,10 @@ extern "C" c_int osqp_amd_batch_update(osqp_amd_batch *b, const c_float *Q, cons
 extern "C" c_int osqp_amd_batch_solve(osqp_amd_batch *b) {
   if (!b) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   BCHK(hipSetDevice(b->device));
-  const int first = b->solves == 0;
   if (b->tile == 8)
-    hipLaunchKernelGGL((k_batch_solve<8, 4>), dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, first);
+    hipLaunchKernelGGL((k_batch_solve<8, 4>), dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, 1);
   else
-    hipLaunchKernelGGL((k_batch_solve<4, 2>), dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, first);
+    hipLaunchKernelGGL((k_batch_solve<4, 2>), dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, 1);
   BCHK(hipGetLastError());
   BCHK(hipStreamSynchronize(b->stream));
   b->solves++;
