@@ -55,9 +55,9 @@ def kernel_roofline(solver, reps=300):
     L.hipeng_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.hipeng_kernel_bytes.restype = C.c_int
     L.hipeng_kernel_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
-    names = ["k_pcg_Ap", "k_pcg_Kp", "k_pcg_update"]
+    names = ["k_cg_A", "k_cg_B"] if os.environ.get("OSQP_AMD_PCG_VARIANT", "1") == "1" else ["k_pcg_Ap", "k_pcg_Kp", "k_pcg_update"]
     rows = []
-    for which in range(3):
+    for which in range(len(names)):
         us = C.c_double(); by = C.c_double()
         assert L.hipeng_time_kernel(solver.engine(), which, reps, C.byref(us)) == 0
         assert L.hipeng_kernel_bytes(solver.engine(), which, C.byref(by)) == 0

@@ -83,6 +83,7 @@ struct State {
   long long admm_done;
   double rz[2];
   double tol2;
+  double gam[2], alp[2];   // Chronopoulos-Gear scalars (ping-pong on parity)
 };
 
 struct Params {          // mutable scalars (host writes, kernels read)
@@ -96,8 +97,10 @@ struct Ctx {             // static pointers / sizes, passed by value
   int gridA, gridM;      // launch grids (>=1) of row kernels over A / over M
   double *xy, *z, *zt, *va, *vb, *q, *l, *u, *rho, *rhoinv, *minv, *pdiag;
   double *r, *zz, *kp, *pt0, *pt1, *dxy, *dy, *cvec;
+  double *init_r, *init_z;        // where k_pcg_init puts r0 and Minv r0 (variant dependent)
+  double *r2, *s2, *pdir, *ut, *w; // Chronopoulos-Gear variant: r/s ping-pong (2n), p, [u|t], w = K u
   double *D, *Dinv, *E, *Einv;
-  double *part_rz, *part_rr, *part_bb, *part_pkp, *part_s0, *part_s1, *part_s2;
+  double *part_rz, *part_rr, *part_bb, *part_pkp, *part_s0, *part_s1, *part_s2, *part_gam, *part_del;
   double *scal;          // reduction outputs (see SC_* below)
   State  *st;
   const Params *prm;
@@ -111,6 +114,7 @@ enum {  // slots of Ctx::scal (max slots are bit patterns of non-negative double
   SC_OBJ, SC_DYLHS, SC_QDX,
   SC_COUNT
 };
+#define SCI(x) ((x) * 16)   // one 128-byte line per slot: atomics on different slots do not serialise
 
 // ---------------------------------------------------------------------------
 // wavefront / workgroup reductions (wave = 64 lanes on gfx950)
@@ -134,6 +138,19 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
   return red[4];
 }
 
+// Three sums in one pass (one barrier pair instead of three); results broadcast.
+// `red` holds >= 16 doubles.
+__device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *red) {
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { red[w] = a; red[4 + w] = b; red[8 + w] = c; }
+  __syncthreads();
+  a = (red[0] + red[1]) + (red[2] + red[3]);
+  b = (red[4] + red[5]) + (red[6] + red[7]);
+  c = (red[8] + red[9]) + (red[10] + red[11]);
+}
+
 // Re-reduce up to three arrays of per-workgroup partials (same length).
 template <int NA>
 __device__ __forceinline__ void reduce_parts(const double *a0, const double *a1,
@@ -145,9 +162,10 @@ __device__ __forceinline__ void reduce_parts(const double *a0, const double *a1,
     if (NA > 1) s1 += a1[i];
     if (NA > 2) s2 += a2[i];
   }
-  out[0] = block_sum(s0, red);
-  if (NA > 1) out[1] = block_sum(s1, red);
-  if (NA > 2) out[2] = block_sum(s2, red);
+  if (NA == 1) { out[0] = block_sum(s0, red); return; }
+  block_sum3(s0, s1, s2, red);
+  out[0] = s0; out[1] = s1;
+  if (NA > 2) out[2] = s2;
 }
 
 __device__ __forceinline__ void atomic_max_pos(double *slot, double v) {
@@ -192,6 +210,17 @@ __device__ __forceinline__ double row_sum(const double *l, int a, int b) {
   return s;
 }
 
+// Row segment summed by L adjacent lanes (strided) + xor tree: used by the PCG
+// kernels, where the summation order is free; every lane returns the sum.
+template <int L>
+__device__ __forceinline__ double row_sum_par(const double *l, int a, int b, int lane) {
+  double s = 0.0;
+  for (int k = a + lane; k < b; k += L) s += l[k];
+#pragma unroll
+  for (int o = L / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
+}
+
 // A row that does not fit one chunk: whole-workgroup strided reduction of
 // sum_k val[k]*in[col[k]] over [ka, kb).  (Summation order differs from the
 // sequential reference order; only rows longer than MAX_CHUNK take this path.)
@@ -204,7 +233,7 @@ __device__ __forceinline__ double long_row_dot(const DevMat &Mx, int ka, int kb,
 
 #define LDS_DECL(NV)                                   \
   __shared__ double lprod[(NV) * MAX_CHUNK];           \
-  __shared__ double red[8]
+  __shared__ double red[16]
 
 // ---------------------------------------------------------------------------
 // PCG kernels
@@ -244,14 +273,14 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
         const double bj = base + sB;
         const double rj = bj - prm.sigma * c.va[j] - sA;
         const double zj = c.minv[j] * rj;
-        c.r[j] = rj;
-        c.zz[j] = zj;
+        c.init_r[j] = rj;
+        c.init_z[j] = zj;
         prz += rj * zj; prr += rj * rj; pbb += bj * bj;
       }
     }
     __syncthreads();
   }
-  prz = block_sum(prz, red); prr = block_sum(prr, red); pbb = block_sum(pbb, red);
+  block_sum3(prz, prr, pbb, red);
   if (threadIdx.x == 0) {
     c.part_rz[blockIdx.x] = prz; c.part_rr[blockIdx.x] = prr; c.part_bb[blockIdx.x] = pbb;
     if (blockIdx.x == 0) {
@@ -375,7 +404,7 @@ __global__ void __launch_bounds__(TB) k_pcg_update(Ctx c, int it, int flags) {
   State *st = c.st;
   const bool bench = flags & 4;
   if (!bench && (!st->run || st->done)) return;
-  __shared__ double red[8];
+  __shared__ double red[16];
   double pkp[1];
   reduce_parts<1>(c.part_pkp, nullptr, nullptr, c.gridM, red, pkp);
   double alpha = 0.0;
@@ -393,6 +422,242 @@ __global__ void __launch_bounds__(TB) k_pcg_update(Ctx c, int it, int flags) {
   }
   prz = block_sum(prz, red); prr = block_sum(prr, red);
   if (threadIdx.x == 0) { c.part_rz[blockIdx.x] = prz; c.part_rr[blockIdx.x] = prr; }
+}
+
+// ---------------------------------------------------------------------------
+// Chronopoulos-Gear PCG: two kernels per iteration instead of three.
+//   u = Minv r, w = K u, gamma = (r,u), delta = (w,u)
+//   beta = gamma/gamma_old, alpha = gamma / (delta - beta*gamma/alpha_old)
+//   p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s
+// k_cg_A does the vector update for its own slice AND t = rho.(A u_new), with
+// u_new recomputed from (r_old, w, s_old, Minv) at every gathered column (same
+// expression, hence the same bits, as the value the owner stores); r and s are
+// ping-ponged on the parity of `it` so gathers never see half-updated data.
+// k_cg_B applies w = [P|A'][u;t] + sigma u and emits the three dot partials.
+// flags: bit1 = first kernel of a "continue" graph, bit2 = benchmark,
+//        bit3 = "pre" pass (pure operator apply on u0, first convergence test)
+// ---------------------------------------------------------------------------
+#define EPT (MAX_CHUNK / TB)
+
+template <int RL>   // lanes per row segment
+__global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
+  State *st = c.st;
+  const bool cont = flags & 2, bench = flags & 4, pre = flags & 8;
+  // ---- issue every independent load before looking at the flags ----
+  const int stalled = st->stalled, run = st->run, done = st->done, neg = st->neg_curv;
+  const int iters_prev = st->iters[(it + 1) & 1];
+  const double tol2_old = st->tol2, gam_old = st->gam[(it + 1) & 1], alp_old = st->alp[(it + 1) & 1];
+  const Params prm = *c.prm;
+  const bool has_blk = (int)blockIdx.x < c.A.nblk;
+  RowBlk b = {0, 0, 0, 0};
+  if (has_blk) b = c.A.blk[blockIdx.x];
+  const int cnt = b.k1 - b.k0;
+  const bool small = has_blk && cnt <= MAX_CHUNK;
+  const double *rold = c.r2 + ((it + 1) & 1) * c.n, *sold = c.s2 + ((it + 1) & 1) * c.n;
+  double *rnew = c.r2 + (it & 1) * c.n, *snew = c.s2 + (it & 1) * c.n;
+  int ecol[EPT]; double eval[EPT], g0[EPT], g1[EPT], g2[EPT], g3[EPT];
+  const int rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
+  int rp0 = 0, rp1 = 0;
+  if (small) {
+    if (b.r0 + rg < b.r1) { rp0 = c.A.rowptr[b.r0 + rg]; rp1 = c.A.rowptr[b.r0 + rg + 1]; }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int k = threadIdx.x + e * TB;
+      if (k < cnt) { ecol[e] = c.A.col[b.k0 + k]; eval[e] = c.A.val[b.k0 + k]; }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int k = threadIdx.x + e * TB;
+      if (k < cnt) {
+        const int cc = ecol[e];
+        if (pre) g0[e] = c.ut[cc];
+        else { g0[e] = rold[cc]; g1[e] = c.w[cc]; g2[e] = sold[cc]; g3[e] = c.minv[cc]; }
+      }
+    }
+  }
+  // dot-product partials of the previous kernel (pre: rr, bb ; else: rr, gamma, delta)
+  double q0 = 0, q1 = 0, q2 = 0;
+  {
+    const double *a1 = pre ? c.part_bb : c.part_gam;
+    for (int i = threadIdx.x; i < c.gridM; i += TB) { q0 += c.part_rr[i]; q1 += a1[i]; if (!pre) q2 += c.part_del[i]; }
+  }
+  const int j0 = blockIdx.x * TB + threadIdx.x;
+  double o_u = 0, o_w = 0, o_p = 0, o_s = 0, o_r = 0, o_x = 0, o_m = 0;
+  if (!pre && j0 < c.n) {
+    o_u = c.ut[j0]; o_w = c.w[j0]; o_p = c.pdir[j0]; o_s = sold[j0]; o_r = rold[j0]; o_x = c.va[j0]; o_m = c.minv[j0];
+  }
+  if (cont) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->run = stalled;
+    if (!stalled) return;
+  } else if (!bench && (!run || done)) return;
+  LDS_DECL(1);
+  double sums[3];
+  bool first = false;
+  double alpha = 0.0, beta = 0.0, tol2 = tol2_old;
+  sums[0] = q0; sums[1] = q1; sums[2] = q2;
+  block_sum3(sums[0], sums[1], sums[2], red);
+  if (pre) {
+    tol2 = fmax(prm.eps_rel * prm.eps_rel * sums[1], prm.eps_abs * prm.eps_abs);
+    if (!bench && sums[0] <= tol2) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->tol2 = tol2; }
+      return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->tol2 = tol2; st->gam[1] = 0.0; st->alp[1] = 0.0; }
+  } else {
+    const double rr = sums[0], gam = sums[1], del = sums[2];
+    first = gam_old == 0.0;            // the pre pass zeroes gam[1]: first update of this solve
+    if (first) { beta = 0.0; alpha = gam / del; }
+    else { beta = gam / gam_old; alpha = gam / (del - beta * gam / alp_old); }
+    if (bench) { beta = 0.5; alpha = 1e-3; }
+    const bool conv = rr <= tol2;
+    const bool bad = !(alpha > 0.0) || !(del > 0.0);      // breakdown / negative curvature
+    const bool giveup = iters_prev >= prm.pcg_max_iter || neg || bad;
+    if (!bench && (conv || giveup)) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = conv ? 1 : 2; if (bad && !conv) st->neg_curv = 1; }
+      return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      st->gam[it & 1] = gam; st->alp[it & 1] = alpha; st->iters[it & 1] = iters_prev + 1;
+    }
+    // own slice: p, s, x, r, u (first element per thread was prefetched above)
+    for (int j = j0; j < c.n; j += gridDim.x * TB) {
+      double uj, wj, po, so, ro, xo, mi;
+      if (j == j0) { uj = o_u; wj = o_w; po = o_p; so = o_s; ro = o_r; xo = o_x; mi = o_m; }
+      else { uj = c.ut[j]; wj = c.w[j]; po = c.pdir[j]; so = sold[j]; ro = rold[j]; xo = c.va[j]; mi = c.minv[j]; }
+      const double pj = first ? uj : (uj + beta * po);
+      const double sj = first ? wj : (wj + beta * so);
+      const double rj = ro - alpha * sj;
+      c.pdir[j] = pj; snew[j] = sj; rnew[j] = rj;
+      c.va[j] = xo + alpha * pj;
+      c.ut[j] = mi * rj;
+    }
+  }
+  // ---- t = rho . (A u_new) ----
+  double *t = c.ut + c.n;
+  for (int bi = blockIdx.x; bi < c.A.nblk; bi += gridDim.x) {
+    if (bi != (int)blockIdx.x) b = c.A.blk[bi];
+    const int cn = b.k1 - b.k0;
+    if (cn > MAX_CHUNK) {            // single long row: strided dot by the whole workgroup
+      double acc = 0.0;
+      for (int k = b.k0 + threadIdx.x; k < b.k1; k += TB) {
+        const int cc = c.A.col[k];
+        double uv;
+        if (pre) uv = c.ut[cc];
+        else {
+          const double sj = first ? c.w[cc] : (c.w[cc] + beta * sold[cc]);
+          uv = c.minv[cc] * (rold[cc] - alpha * sj);
+        }
+        acc += c.A.val[k] * uv;
+      }
+      acc = block_sum(acc, red);
+      if (threadIdx.x == 0) t[b.r0] = c.rho[b.r0] * acc;
+    } else {
+      if (bi == (int)blockIdx.x) {   // prefetched entries
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const int k = threadIdx.x + e * TB;
+          if (k < cn) {
+            double uv;
+            if (pre) uv = g0[e];
+            else {
+              const double sj = first ? g1[e] : (g1[e] + beta * g2[e]);
+              uv = g3[e] * (g0[e] - alpha * sj);
+            }
+            lprod[k] = eval[e] * uv;
+          }
+        }
+      } else {
+        for (int k = threadIdx.x; k < cn; k += TB) {
+          const int cc = c.A.col[b.k0 + k];
+          double uv;
+          if (pre) uv = c.ut[cc];
+          else {
+            const double sj = first ? c.w[cc] : (c.w[cc] + beta * sold[cc]);
+            uv = c.minv[cc] * (rold[cc] - alpha * sj);
+          }
+          lprod[k] = c.A.val[b.k0 + k] * uv;
+        }
+      }
+      __syncthreads();
+      for (int i = b.r0 + rg; i < b.r1; i += TB / RL) {
+        int a0, a1;
+        if (bi == (int)blockIdx.x && i == b.r0 + rg) { a0 = rp0; a1 = rp1; }
+        else { a0 = c.A.rowptr[i]; a1 = c.A.rowptr[i + 1]; }
+        const double acc = row_sum_par<RL>(lprod, a0 - b.k0, a1 - b.k0, rlane);
+        if (rlane == 0) t[i] = c.rho[i] * acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int RL>
+__global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
+  if (flags & 64) return;                                                            // timing probe: empty kernel
+  State *st = c.st;
+  const bool bench = flags & 4;
+  const int run = st->run, done = st->done;
+  const double sigma = c.prm->sigma;
+  const bool has_blk = (int)blockIdx.x < c.M.nblk;
+  RowBlk b = {0, 0, 0, 0};
+  if (has_blk) b = c.M.blk[blockIdx.x];
+  const int cnt = b.k1 - b.k0;
+  const bool small = has_blk && cnt <= MAX_CHUNK;
+  double ev[EPT];
+  const int rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
+  int rp0 = 0, rp1 = 0;
+  if (small) {
+    if (b.r0 + rg < b.r1) { rp0 = c.M.rowptr[b.r0 + rg]; rp1 = c.M.rowptr[b.r0 + rg + 1]; }
+    int ecol[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int k = threadIdx.x + e * TB;
+      if (k < cnt) { ecol[e] = c.M.col[b.k0 + k]; ev[e] = c.M.val[b.k0 + k]; }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int k = threadIdx.x + e * TB;
+      if (k < cnt) ev[e] = ev[e] * c.ut[ecol[e]];
+    }
+  }
+  if (!bench && (!run || done)) return;
+  if (flags & 16) { if (ev[0] == 12345.678 && run == 77) c.w[0] = ev[1]; return; }   // timing probe: launch + prefetch only
+  LDS_DECL(1);
+  const double *r = c.r2 + (it & 1) * c.n;
+  double pg = 0, pd = 0, prr = 0;
+  for (int bi = blockIdx.x; bi < c.M.nblk; bi += gridDim.x) {
+    if (bi != (int)blockIdx.x) b = c.M.blk[bi];
+    const int cn = b.k1 - b.k0;
+    if (cn > MAX_CHUNK) {
+      const double acc = long_row_dot(c.M, b.k0, b.k1, c.ut, red);
+      if (threadIdx.x == 0) {
+        const int j = b.r0;
+        const double uj = c.ut[j], wj = acc + sigma * uj, rj = r[j];
+        c.w[j] = wj; pg += rj * uj; pd += wj * uj; prr += rj * rj;
+      }
+    } else {
+      if (bi == (int)blockIdx.x) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { const int k = threadIdx.x + e * TB; if (k < cn) lprod[k] = ev[e]; }
+      } else stage_products<1>(c.M, b, c.ut, nullptr, lprod, nullptr);
+      __syncthreads();
+      for (int j = b.r0 + rg; j < b.r1; j += TB / RL) {
+        int a0, a1;
+        if (bi == (int)blockIdx.x && j == b.r0 + rg) { a0 = rp0; a1 = rp1; }
+        else { a0 = c.M.rowptr[j]; a1 = c.M.rowptr[j + 1]; }
+        const double acc = row_sum_par<RL>(lprod, a0 - b.k0, a1 - b.k0, rlane);
+        if (rlane == 0) {
+          const double uj = c.ut[j], wj = acc + sigma * uj, rj = r[j];
+          c.w[j] = wj;
+          pg += rj * uj; pd += wj * uj; prr += rj * rj;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (flags & 32) { if (pg == 12345.678) c.w[0] = pd + prr; return; }                // timing probe: no block reductions
+  block_sum3(pg, pd, prr, red);
+  if (threadIdx.x == 0) { c.part_gam[blockIdx.x] = pg; c.part_del[blockIdx.x] = pd; c.part_rr[blockIdx.x] = prr; }
 }
 
 // Last kernel of an ADMM iteration: z~ = A x~, then update_x / update_z (+project)
@@ -547,10 +812,10 @@ __global__ void __launch_bounds__(TB) k_residuals(Ctx c) {
       }
       __syncthreads();
     }
-    block_max_to(m_pu, c.scal + SC_PRI_U, red); block_max_to(m_ps, c.scal + SC_PRI_S, red);
-    block_max_to(m_zu, c.scal + SC_Z_U, red);   block_max_to(m_zs, c.scal + SC_Z_S, red);
-    block_max_to(m_au, c.scal + SC_AX_U, red);  block_max_to(m_as, c.scal + SC_AX_S, red);
-    block_max_to(m_du, c.scal + SC_DYN_U, red); block_max_to(m_ds, c.scal + SC_DYN_S, red);
+    block_max_to(m_pu, c.scal + SCI(SC_PRI_U), red); block_max_to(m_ps, c.scal + SCI(SC_PRI_S), red);
+    block_max_to(m_zu, c.scal + SCI(SC_Z_U), red);   block_max_to(m_zs, c.scal + SCI(SC_Z_S), red);
+    block_max_to(m_au, c.scal + SCI(SC_AX_U), red);  block_max_to(m_as, c.scal + SCI(SC_AX_S), red);
+    block_max_to(m_du, c.scal + SCI(SC_DYN_U), red); block_max_to(m_ds, c.scal + SCI(SC_DYN_S), red);
     lhs = block_sum(lhs, red);
     if (threadIdx.x == 0) c.part_s0[blockIdx.x] = lhs;
     return;
@@ -588,25 +853,25 @@ __global__ void __launch_bounds__(TB) k_residuals(Ctx c) {
     }
     __syncthreads();
   }
-  block_max_to(m_du, c.scal + SC_DUA_U, red); block_max_to(m_ds, c.scal + SC_DUA_S, red);
-  block_max_to(m_qu, c.scal + SC_Q_U, red);   block_max_to(m_qs, c.scal + SC_Q_S, red);
-  block_max_to(m_tu, c.scal + SC_ATY_U, red); block_max_to(m_ts, c.scal + SC_ATY_S, red);
-  block_max_to(m_pu, c.scal + SC_PX_U, red);  block_max_to(m_ps, c.scal + SC_PX_S, red);
-  block_max_to(m_xu, c.scal + SC_DXN_U, red); block_max_to(m_xs, c.scal + SC_DXN_S, red);
+  block_max_to(m_du, c.scal + SCI(SC_DUA_U), red); block_max_to(m_ds, c.scal + SCI(SC_DUA_S), red);
+  block_max_to(m_qu, c.scal + SCI(SC_Q_U), red);   block_max_to(m_qs, c.scal + SCI(SC_Q_S), red);
+  block_max_to(m_tu, c.scal + SCI(SC_ATY_U), red); block_max_to(m_ts, c.scal + SCI(SC_ATY_S), red);
+  block_max_to(m_pu, c.scal + SCI(SC_PX_U), red);  block_max_to(m_ps, c.scal + SCI(SC_PX_S), red);
+  block_max_to(m_xu, c.scal + SCI(SC_DXN_U), red); block_max_to(m_xs, c.scal + SCI(SC_DXN_S), red);
   obj = block_sum(obj, red); qdx = block_sum(qdx, red);
   if (threadIdx.x == 0) { c.part_s1[bid] = obj; c.part_s2[bid] = qdx; }
 }
 
 // Fixed-order final sums of the three partial arrays above (one workgroup).
 __global__ void __launch_bounds__(TB) k_final_sums(Ctx c) {
-  __shared__ double red[8];
+  __shared__ double red[16];
   double s[1];
   reduce_parts<1>(c.part_s0, nullptr, nullptr, c.gridA, red, s);
-  if (threadIdx.x == 0) c.scal[SC_DYLHS] = s[0];
+  if (threadIdx.x == 0) c.scal[SCI(SC_DYLHS)] = s[0];
   reduce_parts<1>(c.part_s1, nullptr, nullptr, c.gridM, red, s);
-  if (threadIdx.x == 0) c.scal[SC_OBJ] = s[0];
+  if (threadIdx.x == 0) c.scal[SCI(SC_OBJ)] = s[0];
   reduce_parts<1>(c.part_s2, nullptr, nullptr, c.gridM, red, s);
-  if (threadIdx.x == 0) c.scal[SC_QDX] = s[0];
+  if (threadIdx.x == 0) c.scal[SCI(SC_QDX)] = s[0];
 }
 
 // Second stage of the infeasibility tests (auxil.c:401-417, 456-497):
@@ -632,7 +897,7 @@ __global__ void __launch_bounds__(TB) k_certificates(Ctx c, double eps_dx, int u
       __syncthreads();
     }
     viol = block_sum(viol, red);
-    if (threadIdx.x == 0 && viol > 0) atomic_max_pos(c.scal + SC_ADX_VIOL, viol);
+    if (threadIdx.x == 0 && viol > 0) atomic_max_pos(c.scal + SCI(SC_ADX_VIOL), viol);
     return;
   }
   const int bid = blockIdx.x - c.gridA;
@@ -659,8 +924,8 @@ __global__ void __launch_bounds__(TB) k_certificates(Ctx c, double eps_dx, int u
     }
     __syncthreads();
   }
-  block_max_to(m_tu, c.scal + SC_ATDY_U, red); block_max_to(m_ts, c.scal + SC_ATDY_S, red);
-  block_max_to(m_pu, c.scal + SC_PDX_U, red);  block_max_to(m_ps, c.scal + SC_PDX_S, red);
+  block_max_to(m_tu, c.scal + SCI(SC_ATDY_U), red); block_max_to(m_ts, c.scal + SCI(SC_ATDY_S), red);
+  block_max_to(m_pu, c.scal + SCI(SC_PDX_U), red);  block_max_to(m_ps, c.scal + SCI(SC_PDX_S), red);
 }
 
 // ---------------------------------------------------------------------------
@@ -691,6 +956,8 @@ struct hipeng {
   std::vector<void *> allocs;
   std::map<int, hipGraphExec_t> graphs, cgraphs;
   int K = 8;
+  int variant = 1;
+  int rlA = 8, rlM = 8;   // lanes per row segment in the PCG kernels
   bool calibrated = false;
   hipeng_stats stats{};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -716,17 +983,18 @@ static void build_blocks(HostMat &H, int chunk) {
   while (r < H.nrows) {
     int r1 = r + 1;
     const int k0 = H.rowptr[r];
-    while (r1 < H.nrows && H.rowptr[r1 + 1] - k0 <= chunk && (r1 - r) < 4 * TB) r1++;
+    while (r1 < H.nrows && H.rowptr[r1 + 1] - k0 <= chunk && (r1 - r) < 8 * TB) r1++;
     H.blk.push_back({r, r1, k0, H.rowptr[r1]});
     r = r1;
   }
 }
 
 static int pick_chunk(long long nnz, int nrows) {
-  // enough workgroups to cover 256 CUs several times on small problems,
-  // full 2048-product chunks once the matrix is large
-  int chunk = MAX_CHUNK;
-  while (chunk > 256 && nnz / chunk < 1024) chunk >>= 1;
+  // about one to two workgroups per CU on small problems (every workgroup of a
+  // consumer kernel re-reduces one dot partial per producer workgroup, so the
+  // grid is kept near the CU count), full 2048-product chunks on large ones
+  int chunk = 256;
+  while (chunk < MAX_CHUNK && nnz / chunk > 384) chunk <<= 1;
   (void)nrows;
   return chunk;
 }
@@ -863,6 +1131,14 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   HIPCHK(hipEventCreate(&e->ev1));
   build_A(e, A);
   build_M(e, P, A);
+  auto pick_rl = [](const HostMat &H) {
+    int maxrows = 1;
+    for (const RowBlk &b : H.blk) maxrows = std::max(maxrows, b.r1 - b.r0);
+    int rl = 8;
+    while (rl > 1 && TB / rl < maxrows) rl >>= 1;   // one pass over the block's rows if possible
+    return rl;
+  };
+  e->rlA = pick_rl(e->A); e->rlM = pick_rl(e->M);
   if (upload_mat(e, e->A) || upload_mat(e, e->M)) return HIPENG_ERR_HIP;
   Ctx &c = e->c;
   c.n = n; c.m = m;
@@ -874,13 +1150,20 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   DA(q, n); DA(l, m); DA(u, m); DA(rho, m); DA(rhoinv, m); DA(minv, n); DA(pdiag, n);
   DA(r, n); DA(zz, n); DA(kp, n); DA(pt0, n + m); DA(pt1, n + m);
   DA(dxy, n + m); DA(dy, m); DA(cvec, n);
+  DA(r2, 2 * n); DA(s2, 2 * n); DA(pdir, n); DA(ut, n + m); DA(w, n);
   DA(D, n); DA(Dinv, n); DA(E, m); DA(Einv, m);
   const int np = std::max(c.gridM, c.gridA);
   DA(part_rz, np); DA(part_rr, np); DA(part_bb, np); DA(part_pkp, np);
-  DA(part_s0, np); DA(part_s1, np); DA(part_s2, np);
-  DA(scal, SC_COUNT);
+  DA(part_s0, np); DA(part_s1, np); DA(part_s2, np); DA(part_gam, np); DA(part_del, np);
+  DA(scal, SC_COUNT * 16);
   DA(st, 1);
 #undef DA
+  {
+    const char *v = getenv("OSQP_AMD_PCG_VARIANT");
+    e->variant = v ? atoi(v) : 1;          // 1 = Chronopoulos-Gear (2 kernels / iteration), 0 = classic (3)
+    if (e->variant == 1) { c.init_r = c.r2 + n; c.init_z = c.ut; }
+    else { c.init_r = c.r; c.init_z = c.zz; }
+  }
   if (dev_alloc(e, &e->d_prm, 1)) return HIPENG_ERR_HIP;
   c.prm = e->d_prm;
   e->prm.sigma = prm->sigma; e->prm.alpha = prm->alpha;
@@ -890,7 +1173,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   if (push_params(e)) return HIPENG_ERR_HIP;
   if (upload_vec(e, c.q, q, n) || upload_vec(e, c.l, l, m) || upload_vec(e, c.u, u, m) ||
       upload_vec(e, c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
-  e->stats.kernels_per_pcg_iter = 3;
+  e->stats.kernels_per_pcg_iter = e->variant == 1 ? 2 : 3;
   *out = e;
   if (rho_vec) { int rc = hipeng_upload_rho(e, rho_vec); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1057,8 +1340,32 @@ extern "C" int hipeng_set_z(hipeng *e, const c_float *z) {
 }
 
 // ---- graphs ---------------------------------------------------------------
+static void launch_cg_A(hipeng *e, int it, int flags) {
+  const Ctx &c = e->c;
+  switch (e->rlA) {
+  case 1: hipLaunchKernelGGL(k_cg_A<1>, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, flags); break;
+  case 2: hipLaunchKernelGGL(k_cg_A<2>, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, flags); break;
+  case 4: hipLaunchKernelGGL(k_cg_A<4>, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, flags); break;
+  default: hipLaunchKernelGGL(k_cg_A<8>, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, flags); break;
+  }
+}
+static void launch_cg_B(hipeng *e, int it, int flags) {
+  const Ctx &c = e->c;
+  switch (e->rlM) {
+  case 1: hipLaunchKernelGGL(k_cg_B<1>, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags); break;
+  case 2: hipLaunchKernelGGL(k_cg_B<2>, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags); break;
+  case 4: hipLaunchKernelGGL(k_cg_B<4>, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags); break;
+  default: hipLaunchKernelGGL(k_cg_B<8>, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags); break;
+  }
+}
+
 static void launch_pcg_iter(hipeng *e, int it, int flags) {
   const Ctx &c = e->c;
+  if (e->variant == 1) {
+    launch_cg_A(e, it, flags & ~1);
+    launch_cg_B(e, it, flags & 4);
+    return;
+  }
   hipLaunchKernelGGL(k_pcg_Ap, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, flags);
   hipLaunchKernelGGL(k_pcg_Kp, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags & 4);
   hipLaunchKernelGGL(k_pcg_update, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags & 4);
@@ -1073,10 +1380,14 @@ static int get_graph(hipeng *e, int K, bool cont, hipGraphExec_t *out) {
   HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
   if (!cont) {
     hipLaunchKernelGGL(k_pcg_init, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c);
+    if (e->variant == 1) {   // operator apply on u0 (+ first convergence test), then w0 and the first dots
+      launch_cg_A(e, -1, 8);
+      launch_cg_B(e, -1, 0);
+    }
     for (int it = 0; it < K; it++) launch_pcg_iter(e, it, it == 0 ? 1 : 0);
   } else {
     // resumes at an even iteration index (K is always even): parity of the
-    // p / rz ping-pong buffers is preserved
+    // ping-pong buffers / scalars is preserved
     for (int it = 0; it < K; it++) launch_pcg_iter(e, it + 2, it == 0 ? 2 : 0);
   }
   hipLaunchKernelGGL(k_admm_finalize, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c);
@@ -1155,27 +1466,27 @@ extern "C" int hipeng_get_stats(hipeng *e, hipeng_stats *st) {
 
 // ---- residual scalars -----------------------------------------------------
 static void fill_scalars(const double *h, hipeng_scalars *o) {
-  o->pri_res_u = h[SC_PRI_U]; o->pri_res_s = h[SC_PRI_S];
-  o->z_u = h[SC_Z_U]; o->z_s = h[SC_Z_S]; o->Ax_u = h[SC_AX_U]; o->Ax_s = h[SC_AX_S];
-  o->dua_res_u = h[SC_DUA_U]; o->dua_res_s = h[SC_DUA_S];
-  o->q_u = h[SC_Q_U]; o->q_s = h[SC_Q_S]; o->Aty_u = h[SC_ATY_U]; o->Aty_s = h[SC_ATY_S];
-  o->Px_u = h[SC_PX_U]; o->Px_s = h[SC_PX_S];
-  o->obj_scaled = h[SC_OBJ];
-  o->dy_norm_u = h[SC_DYN_U]; o->dy_norm_s = h[SC_DYN_S]; o->dy_lhs = h[SC_DYLHS];
-  o->dx_norm_u = h[SC_DXN_U]; o->dx_norm_s = h[SC_DXN_S]; o->q_dx = h[SC_QDX];
-  o->Atdy_u = h[SC_ATDY_U]; o->Atdy_s = h[SC_ATDY_S];
-  o->Pdx_u = h[SC_PDX_U]; o->Pdx_s = h[SC_PDX_S];
-  o->Adx_viol = h[SC_ADX_VIOL];
+  o->pri_res_u = h[SCI(SC_PRI_U)]; o->pri_res_s = h[SCI(SC_PRI_S)];
+  o->z_u = h[SCI(SC_Z_U)]; o->z_s = h[SCI(SC_Z_S)]; o->Ax_u = h[SCI(SC_AX_U)]; o->Ax_s = h[SCI(SC_AX_S)];
+  o->dua_res_u = h[SCI(SC_DUA_U)]; o->dua_res_s = h[SCI(SC_DUA_S)];
+  o->q_u = h[SCI(SC_Q_U)]; o->q_s = h[SCI(SC_Q_S)]; o->Aty_u = h[SCI(SC_ATY_U)]; o->Aty_s = h[SCI(SC_ATY_S)];
+  o->Px_u = h[SCI(SC_PX_U)]; o->Px_s = h[SCI(SC_PX_S)];
+  o->obj_scaled = h[SCI(SC_OBJ)];
+  o->dy_norm_u = h[SCI(SC_DYN_U)]; o->dy_norm_s = h[SCI(SC_DYN_S)]; o->dy_lhs = h[SCI(SC_DYLHS)];
+  o->dx_norm_u = h[SCI(SC_DXN_U)]; o->dx_norm_s = h[SCI(SC_DXN_S)]; o->q_dx = h[SCI(SC_QDX)];
+  o->Atdy_u = h[SCI(SC_ATDY_U)]; o->Atdy_s = h[SCI(SC_ATDY_S)];
+  o->Pdx_u = h[SCI(SC_PDX_U)]; o->Pdx_s = h[SCI(SC_PDX_S)];
+  o->Adx_viol = h[SCI(SC_ADX_VIOL)];
 }
 
 extern "C" int hipeng_residuals(hipeng *e, hipeng_scalars *out) {
   if (!e || !out) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipMemsetAsync(e->c.scal, 0, SC_COUNT * sizeof(double), e->stream));
+  HIPCHK(hipMemsetAsync(e->c.scal, 0, SC_COUNT * 16 * sizeof(double), e->stream));
   hipLaunchKernelGGL(k_residuals, dim3(e->c.gridA + e->c.gridM), dim3(TB), 0, e->stream, e->c);
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(TB), 0, e->stream, e->c);
   HIPCHK(hipGetLastError());
-  double h[SC_COUNT];
+  double h[SCI(SC_COUNT)];
   HIPCHK(hipMemcpyAsync(h, e->c.scal, sizeof(h), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   fill_scalars(h, out);
@@ -1185,15 +1496,15 @@ extern "C" int hipeng_residuals(hipeng *e, hipeng_scalars *out) {
 extern "C" int hipeng_certificates(hipeng *e, c_float eps_dx, int unscaled, hipeng_scalars *io) {
   if (!e || !io) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipMemsetAsync(e->c.scal + SC_ATDY_U, 0, 5 * sizeof(double), e->stream));
+  HIPCHK(hipMemsetAsync(e->c.scal + SCI(SC_ATDY_U), 0, 5 * sizeof(double), e->stream));
   hipLaunchKernelGGL(k_certificates, dim3(e->c.gridA + e->c.gridM), dim3(TB), 0, e->stream, e->c,
                      (double)eps_dx, unscaled);
   HIPCHK(hipGetLastError());
-  double h[SC_COUNT];
+  double h[SCI(SC_COUNT)];
   HIPCHK(hipMemcpyAsync(h, e->c.scal, sizeof(h), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  io->Atdy_u = h[SC_ATDY_U]; io->Atdy_s = h[SC_ATDY_S];
-  io->Pdx_u = h[SC_PDX_U]; io->Pdx_s = h[SC_PDX_S]; io->Adx_viol = h[SC_ADX_VIOL];
+  io->Atdy_u = h[SCI(SC_ATDY_U)]; io->Atdy_s = h[SCI(SC_ATDY_S)];
+  io->Pdx_u = h[SCI(SC_PDX_U)]; io->Pdx_s = h[SCI(SC_PDX_S)]; io->Adx_viol = h[SCI(SC_ADX_VIOL)];
   return 0;
 }
 
@@ -1261,11 +1572,16 @@ extern "C" int hipeng_spmv(hipeng *e, int which, const c_float *x, c_float *y) {
 }
 
 extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) {
+  const int dbg = (which >> 8) & 0xff;
+  which &= 0xff;
   if (!e || !usec || reps <= 0 || which < 0 || which > 2) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   const Ctx &c = e->c;
   auto one = [&](int it) {
-    if (which == 0) hipLaunchKernelGGL(k_pcg_Ap, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, 4);
+    if (e->variant == 1) {
+      if (which == 0) launch_cg_A(e, it, 4);
+      else launch_cg_B(e, it, 4 | dbg);
+    } else if (which == 0) hipLaunchKernelGGL(k_pcg_Ap, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, 4);
     else if (which == 1) hipLaunchKernelGGL(k_pcg_Kp, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, 4);
     else hipLaunchKernelGGL(k_pcg_update, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, 4);
   };
@@ -1286,6 +1602,14 @@ extern "C" int hipeng_kernel_bytes(hipeng *e, int which, double *bytes) {
   const double nnzA = (double)e->A.val.size(), nnzM = (double)e->M.val.size();
   // device layout: fp64 values + int32 indices (12 B per stored entry), one
   // int32 row pointer per row, fp64 vectors; gathers counted once per vector
+  if (e->variant == 1) {
+    // k_cg_A: A stream; u,w,p,s,r,Minv,x read + p,s,r,x,u written (12n); rho read, t written (2m)
+    if (which == 0)      *bytes = nnzA * 12 + (m + 1) * 4 + 8 * (12 * n + 2 * m);
+    // k_cg_B: [P|A'] stream; [u|t] and r read, w written
+    else if (which == 1) *bytes = nnzM * 12 + (n + 1) * 4 + 8 * ((n + m) + 2 * n);
+    else                 *bytes = 0;
+    return 0;
+  }
   if (which == 0)       *bytes = nnzA * 12 + (m + 1) * 4 + 8 * (3 * n + 2 * m);   // zz,p_old -> p_new ; rho -> t
   else if (which == 1)  *bytes = nnzM * 12 + (n + 1) * 4 + 8 * ((n + m) + n);     // [p|t] -> Kp
   else                  *bytes = 8 * (7 * n);                                     // x~,r,Kp,p,Minv -> x~,r,zz

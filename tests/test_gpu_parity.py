@@ -338,3 +338,26 @@ def test_full_size_config2_properties(gpu_lib):
     slack_lo, slack_hi = Ax - pb["l"], pb["u"] - Ax
     assert np.all(y[slack_hi > 1e-2] <= 1e-6) and np.all(y[slack_lo > 1e-2] >= -1e-6)
     assert s.stats()["pcg_forced"] == 0
+
+
+def test_full_size_config2_matches_oracle_golden(gpu_lib):
+    """BASELINE config 2 at full size against the CPU oracle's result, captured once in the
+    build container (tests/golden/config2_oracle.json, 10 minutes of direct LDL^T; generator
+    tools/make_config2_golden.py): same 125 iterations and rho update, objective 1e-8
+    relative, x and y 1e-6 relative on the stored subsample."""
+    import json, os
+    import osqp_amd
+    from conftest import GOLDEN
+    from osqp_amd.problems import random_sparse_qp
+    g = json.load(open(os.path.join(GOLDEN, "config2_oracle.json")))
+    pb = random_sparse_qp()
+    r = osqp_amd.OSQP().setup(**pb, eps_abs=1e-4, eps_rel=1e-4, adaptive_rho_interval=100).solve()
+    gi = g["info"]
+    assert r.info.status == gi["status"] == "solved"
+    assert r.info.iter == gi["iters"] == 125 and r.info.rho_updates == gi["rho_updates"]
+    assert abs(r.info.obj_val - gi["obj"]) <= 1e-8 * abs(gi["obj"])
+    xs, ys = np.array(g["x_sub"]), np.array(g["y_sub"])
+    assert np.abs(r.x[::10] - xs).max() <= 1e-6 * g["x_inf"]
+    assert np.abs(r.y[::20] - ys).max() <= 1e-6 * g["y_inf"]
+    assert abs(r.info.pri_res - gi["pri"]) <= 1e-4 * gi["pri"] + 1e-9
+    assert abs(r.info.dua_res - gi["dua"]) <= 1e-4 * gi["dua"] + 1e-9
