@@ -67,8 +67,8 @@ def kernel_roofline(solver, reps=300):
     return dict(bound="hbm", achieved=round(dom["gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(dom["gbs"] / HBM_PEAK_GBS, 5), traffic=None, kernel=dom["kernel"],
                 bytes_per_launch=dom["bytes"], usec_per_launch=round(dom["usec"], 3),
-                note="launch-to-launch period of back-to-back launches (includes the ~1.5us "
-                     "dependent-kernel boundary); working set is L2/Infinity-Cache resident at this size",
+                note="launch-to-launch period of %d graph-captured back-to-back launches (includes the "
+                     "dependent-kernel boundary); the 8 MB working set is L2/Infinity-Cache resident" % reps,
                 all_kernels=[dict(kernel=r["kernel"], usec=round(r["usec"], 3), gbs=round(r["gbs"], 2))
                              for r in rows])
 

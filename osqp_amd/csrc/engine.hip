@@ -41,6 +41,7 @@
 
 #define TB 256            // threads per workgroup (4 wavefronts of 64)
 #define MAX_CHUNK 2048    // products staged in LDS per workgroup (x2 for dual stream)
+#define LONG_ROW 512      // a row with at least this many entries gets a workgroup of its own (no LDS staging)
 #define MAX_PARTS 1024    // upper bound on workgroups that emit dot partials
 #define INF_BOUND 1e26    // OSQP_INFTY * MIN_SCALING
 
@@ -58,6 +59,10 @@
 // device-side descriptors
 // ---------------------------------------------------------------------------
 struct RowBlk { int r0, r1, k0, k1; };
+#define IS_LONG(b) ((b).r1 - (b).r0 == 1 && (b).k1 - (b).k0 >= LONG_ROW)
+// per-column record gathered by k_cg_A: one 32-byte access instead of four 8-byte
+// gathers from four arrays (residual, w = K u, s = K p, Jacobi inverse)
+struct __attribute__((aligned(32))) G4 { double r, w, s, m; };
 
 struct DevMat {
   int nrows, nblk;
@@ -98,10 +103,14 @@ struct Ctx {             // static pointers / sizes, passed by value
   double *xy, *z, *zt, *va, *vb, *q, *l, *u, *rho, *rhoinv, *minv, *pdiag;
   double *r, *zz, *kp, *pt0, *pt1, *dxy, *dy, *cvec;
   double *init_r, *init_z;        // where k_pcg_init puts r0 and Minv r0 (variant dependent)
-  double *r2, *s2, *pdir, *ut, *w; // Chronopoulos-Gear variant: r/s ping-pong (2n), p, [u|t], w = K u
+  double *pdir, *ut;               // Chronopoulos-Gear variant: p, [u|t]
+  G4     *g4;                      // ... and {r, w, s, Minv} records, ping-ponged on parity (2n)
+  int     init_stride;             // element stride of init_r (4 when it points into g4)
   double *D, *Dinv, *E, *Einv;
   double *part_rz, *part_rr, *part_bb, *part_pkp, *part_s0, *part_s1, *part_s2, *part_gam, *part_del;
   double *scal;          // reduction outputs (see SC_* below)
+  double *redout;        // big mode: [rr, gamma, delta, bb] reduced by k_reduce_parts
+  int big;               // grids above MAX_PARTS workgroups: partials are reduced by a one-workgroup kernel
   State  *st;
   const Params *prm;
 };
@@ -194,12 +203,25 @@ template <int NV>
 __device__ __forceinline__ void stage_products(const DevMat &Mx, const RowBlk b,
                                                const double *in0, const double *in1,
                                                double *l0, double *l1) {
+  // all index/value loads of the chunk are issued first, then all gathers, then
+  // the LDS writes: up to 2*MAX_CHUNK/TB independent loads in flight per lane
+  constexpr int E = MAX_CHUNK / TB;
   const int cnt = b.k1 - b.k0;
-  for (int k = threadIdx.x; k < cnt; k += TB) {
-    const int c = Mx.col[b.k0 + k];
-    const double v = Mx.val[b.k0 + k];
-    l0[k] = v * in0[c];
-    if (NV == 2) l1[k] = v * in1[c];
+  int cc[E]; double vv[E], x0[E], x1[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int k = threadIdx.x + e * TB;
+    if (k < cnt) { cc[e] = Mx.col[b.k0 + k]; vv[e] = Mx.val[b.k0 + k]; }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int k = threadIdx.x + e * TB;
+    if (k < cnt) { x0[e] = in0[cc[e]]; if (NV == 2) x1[e] = in1[cc[e]]; }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int k = threadIdx.x + e * TB;
+    if (k < cnt) { l0[k] = vv[e] * x0[e]; if (NV == 2) l1[k] = vv[e] * x1[e]; }
   }
 }
 
@@ -212,13 +234,17 @@ __device__ __forceinline__ double row_sum(const double *l, int a, int b) {
 
 // Row segment summed by L adjacent lanes (strided) + xor tree: used by the PCG
 // kernels, where the summation order is free; every lane returns the sum.
-template <int L>
-__device__ __forceinline__ double row_sum_par(const double *l, int a, int b, int lane) {
+__device__ __forceinline__ double row_sum_par(const double *l, int a, int b, int lane, int L) {
   double s = 0.0;
   for (int k = a + lane; k < b; k += L) s += l[k];
-#pragma unroll
-  for (int o = L / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);   // L is a power of two <= 64
   return s;
+}
+// lanes per row for a block: as many as fit one pass over its rows (1..64)
+__device__ __forceinline__ int lanes_for(int nrows) {
+  int L = 64;
+  while (L > 1 && L * nrows > TB) L >>= 1;
+  return L;
 }
 
 // A row that does not fit one chunk: whole-workgroup strided reduction of
@@ -226,9 +252,15 @@ __device__ __forceinline__ double row_sum_par(const double *l, int a, int b, int
 // sequential reference order; only rows longer than MAX_CHUNK take this path.)
 __device__ __forceinline__ double long_row_dot(const DevMat &Mx, int ka, int kb,
                                                const double *in, double *red) {
-  double s = 0.0;
-  for (int k = ka + threadIdx.x; k < kb; k += TB) s += Mx.val[k] * in[Mx.col[k]];
-  return block_sum(s, red);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = ka + threadIdx.x;
+  for (; k + 3 * TB < kb; k += 4 * TB) {          // four independent index/value/gather chains
+    const int c0 = Mx.col[k], c1 = Mx.col[k + TB], c2 = Mx.col[k + 2 * TB], c3 = Mx.col[k + 3 * TB];
+    const double v0 = Mx.val[k], v1 = Mx.val[k + TB], v2 = Mx.val[k + 2 * TB], v3 = Mx.val[k + 3 * TB];
+    s0 += v0 * in[c0]; s1 += v1 * in[c1]; s2 += v2 * in[c2]; s3 += v3 * in[c3];
+  }
+  for (; k < kb; k += TB) s0 += Mx.val[k] * in[Mx.col[k]];
+  return block_sum((s0 + s1) + (s2 + s3), red);
 }
 
 #define LDS_DECL(NV)                                   \
@@ -253,7 +285,7 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
   double prz = 0, prr = 0, pbb = 0;
   for (int bi = blockIdx.x; bi < c.M.nblk; bi += gridDim.x) {
     const RowBlk b = c.M.blk[bi];
-    const bool longrow = (b.k1 - b.k0) > MAX_CHUNK;
+    const bool longrow = IS_LONG(b);
     if (!longrow) {
       stage_products<2>(c.M, b, c.va, c.vb, lprod, lprod + MAX_CHUNK);
       __syncthreads();
@@ -273,7 +305,7 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
         const double bj = base + sB;
         const double rj = bj - prm.sigma * c.va[j] - sA;
         const double zj = c.minv[j] * rj;
-        c.init_r[j] = rj;
+        c.init_r[(size_t)j * c.init_stride] = rj;
         c.init_z[j] = zj;
         prz += rj * zj; prr += rj * rj; pbb += bj * bj;
       }
@@ -342,7 +374,7 @@ __global__ void __launch_bounds__(TB) k_pcg_Ap(Ctx c, int it, int flags) {
   for (int bi = blockIdx.x; bi < c.A.nblk; bi += gridDim.x) {
     const RowBlk b = c.A.blk[bi];
     const int cnt = b.k1 - b.k0;
-    if (cnt > MAX_CHUNK) {   // single long row
+    if (IS_LONG(b)) {   // single long row
       double s = 0.0;
       for (int k = b.k0 + threadIdx.x; k < b.k1; k += TB) {
         const int cc = c.A.col[k];
@@ -377,7 +409,7 @@ __global__ void __launch_bounds__(TB) k_pcg_Kp(Ctx c, int it, int flags) {
   double ppkp = 0.0;
   for (int bi = blockIdx.x; bi < c.M.nblk; bi += gridDim.x) {
     const RowBlk b = c.M.blk[bi];
-    if ((b.k1 - b.k0) > MAX_CHUNK) {
+    if (IS_LONG(b)) {
       const double s = long_row_dot(c.M, b.k0, b.k1, pt, red);
       if (threadIdx.x == 0) {
         const double pj = pt[b.r0], kpj = s + sigma * pj;
@@ -438,11 +470,31 @@ __global__ void __launch_bounds__(TB) k_pcg_update(Ctx c, int it, int flags) {
 //        bit3 = "pre" pass (pure operator apply on u0, first convergence test)
 // ---------------------------------------------------------------------------
 #define EPT (MAX_CHUNK / TB)
+#define BIG_GRID 8192    // workgroup cap in big mode (32 per CU)
 
-template <int RL>   // lanes per row segment
+// Big mode only: fixed-order reduction of the four partial arrays to scalars, so
+// consumers read 4 doubles instead of re-reducing thousands of partials each.
+__global__ void __launch_bounds__(1024) k_reduce_parts(Ctx c) {
+  __shared__ double red[4][16];
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int i = threadIdx.x; i < c.gridM; i += 1024) {
+    s0 += c.part_rr[i]; s1 += c.part_gam[i]; s2 += c.part_del[i]; s3 += c.part_bb[i];
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[0][w] = s0; red[1][w] = s1; red[2][w] = s2; red[3][w] = s3; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0;
+    for (int k = 0; k < 16; ++k) t += red[threadIdx.x][k];
+    c.redout[threadIdx.x] = t;
+  }
+}
+
 __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   State *st = c.st;
-  const bool cont = flags & 2, bench = flags & 4, pre = flags & 8;
+  const bool cont = flags & 2, bench = flags & 4, upd_only = flags & 16, apply_only = flags & 32;
+  const bool pre = (flags & 8) || apply_only;   // gather u directly (no recompute)
   // ---- issue every independent load before looking at the flags ----
   const int stalled = st->stalled, run = st->run, done = st->done, neg = st->neg_curv;
   const int iters_prev = st->iters[(it + 1) & 1];
@@ -452,11 +504,12 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   RowBlk b = {0, 0, 0, 0};
   if (has_blk) b = c.A.blk[blockIdx.x];
   const int cnt = b.k1 - b.k0;
-  const bool small = has_blk && cnt <= MAX_CHUNK;
-  const double *rold = c.r2 + ((it + 1) & 1) * c.n, *sold = c.s2 + ((it + 1) & 1) * c.n;
-  double *rnew = c.r2 + (it & 1) * c.n, *snew = c.s2 + (it & 1) * c.n;
+  const bool small = has_blk && !IS_LONG(b);
+  const G4 *gold = c.g4 + (size_t)((it + 1) & 1) * c.n;
+  G4 *gnew = c.g4 + (size_t)(it & 1) * c.n;
   int ecol[EPT]; double eval[EPT], g0[EPT], g1[EPT], g2[EPT], g3[EPT];
-  const int rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
+  int RL = lanes_for(b.r1 - b.r0);
+  int rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
   int rp0 = 0, rp1 = 0;
   if (small) {
     if (b.r0 + rg < b.r1) { rp0 = c.A.rowptr[b.r0 + rg]; rp1 = c.A.rowptr[b.r0 + rg + 1]; }
@@ -471,20 +524,24 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
       if (k < cnt) {
         const int cc = ecol[e];
         if (pre) g0[e] = c.ut[cc];
-        else { g0[e] = rold[cc]; g1[e] = c.w[cc]; g2[e] = sold[cc]; g3[e] = c.minv[cc]; }
+        else { const G4 g = gold[cc]; g0[e] = g.r; g1[e] = g.w; g2[e] = g.s; g3[e] = g.m; }
       }
     }
   }
   // dot-product partials of the previous kernel (pre: rr, bb ; else: rr, gamma, delta)
   double q0 = 0, q1 = 0, q2 = 0;
-  {
+  if (apply_only) {
+  } else if (!c.big) {
     const double *a1 = pre ? c.part_bb : c.part_gam;
     for (int i = threadIdx.x; i < c.gridM; i += TB) { q0 += c.part_rr[i]; q1 += a1[i]; if (!pre) q2 += c.part_del[i]; }
+  } else if (threadIdx.x == 0) {
+    q0 = c.redout[0]; q1 = pre ? c.redout[3] : c.redout[1]; q2 = pre ? 0.0 : c.redout[2];
   }
   const int j0 = blockIdx.x * TB + threadIdx.x;
   double o_u = 0, o_w = 0, o_p = 0, o_s = 0, o_r = 0, o_x = 0, o_m = 0;
   if (!pre && j0 < c.n) {
-    o_u = c.ut[j0]; o_w = c.w[j0]; o_p = c.pdir[j0]; o_s = sold[j0]; o_r = rold[j0]; o_x = c.va[j0]; o_m = c.minv[j0];
+    const G4 g = gold[j0];
+    o_u = c.ut[j0]; o_w = g.w; o_p = c.pdir[j0]; o_s = g.s; o_r = g.r; o_x = c.va[j0]; o_m = g.m;
   }
   if (cont) {
     if (blockIdx.x == 0 && threadIdx.x == 0) st->run = stalled;
@@ -495,8 +552,10 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   bool first = false;
   double alpha = 0.0, beta = 0.0, tol2 = tol2_old;
   sums[0] = q0; sums[1] = q1; sums[2] = q2;
-  block_sum3(sums[0], sums[1], sums[2], red);
-  if (pre) {
+  if (!apply_only) block_sum3(sums[0], sums[1], sums[2], red);
+  if (apply_only) {
+    // second half of a split iteration: the update kernel before this one did the scalars
+  } else if (pre) {
     tol2 = fmax(prm.eps_rel * prm.eps_rel * sums[1], prm.eps_abs * prm.eps_abs);
     if (!bench && sums[0] <= tol2) {
       if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->tol2 = tol2; }
@@ -523,29 +582,34 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
     for (int j = j0; j < c.n; j += gridDim.x * TB) {
       double uj, wj, po, so, ro, xo, mi;
       if (j == j0) { uj = o_u; wj = o_w; po = o_p; so = o_s; ro = o_r; xo = o_x; mi = o_m; }
-      else { uj = c.ut[j]; wj = c.w[j]; po = c.pdir[j]; so = sold[j]; ro = rold[j]; xo = c.va[j]; mi = c.minv[j]; }
+      else { const G4 g = gold[j]; uj = c.ut[j]; wj = g.w; po = c.pdir[j]; so = g.s; ro = g.r; xo = c.va[j]; mi = g.m; }
       const double pj = first ? uj : (uj + beta * po);
       const double sj = first ? wj : (wj + beta * so);
       const double rj = ro - alpha * sj;
-      c.pdir[j] = pj; snew[j] = sj; rnew[j] = rj;
+      c.pdir[j] = pj; gnew[j].s = sj; gnew[j].r = rj;
       c.va[j] = xo + alpha * pj;
       c.ut[j] = mi * rj;
     }
   }
+  if (upd_only) return;
   // ---- t = rho . (A u_new) ----
   double *t = c.ut + c.n;
   for (int bi = blockIdx.x; bi < c.A.nblk; bi += gridDim.x) {
-    if (bi != (int)blockIdx.x) b = c.A.blk[bi];
+    if (bi != (int)blockIdx.x) { b = c.A.blk[bi]; RL = lanes_for(b.r1 - b.r0); rg = threadIdx.x / RL; rlane = threadIdx.x % RL; }
     const int cn = b.k1 - b.k0;
-    if (cn > MAX_CHUNK) {            // single long row: strided dot by the whole workgroup
+    if (IS_LONG(b) && pre) {         // single long row, plain gather of u
+      const double acc = long_row_dot(c.A, b.k0, b.k1, c.ut, red);
+      if (threadIdx.x == 0) t[b.r0] = c.rho[b.r0] * acc;
+    } else if (IS_LONG(b)) {         // single long row: strided dot by the whole workgroup
       double acc = 0.0;
       for (int k = b.k0 + threadIdx.x; k < b.k1; k += TB) {
         const int cc = c.A.col[k];
         double uv;
         if (pre) uv = c.ut[cc];
         else {
-          const double sj = first ? c.w[cc] : (c.w[cc] + beta * sold[cc]);
-          uv = c.minv[cc] * (rold[cc] - alpha * sj);
+          const G4 g = gold[cc];
+          const double sj = first ? g.w : (g.w + beta * g.s);
+          uv = g.m * (g.r - alpha * sj);
         }
         acc += c.A.val[k] * uv;
       }
@@ -567,15 +631,32 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
           }
         }
       } else {
-        for (int k = threadIdx.x; k < cn; k += TB) {
-          const int cc = c.A.col[b.k0 + k];
-          double uv;
-          if (pre) uv = c.ut[cc];
-          else {
-            const double sj = first ? c.w[cc] : (c.w[cc] + beta * sold[cc]);
-            uv = c.minv[cc] * (rold[cc] - alpha * sj);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const int k = threadIdx.x + e * TB;
+          if (k < cn) { ecol[e] = c.A.col[b.k0 + k]; eval[e] = c.A.val[b.k0 + k]; }
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const int k = threadIdx.x + e * TB;
+          if (k < cn) {
+            const int cc = ecol[e];
+            if (pre) g0[e] = c.ut[cc];
+            else { const G4 g = gold[cc]; g0[e] = g.r; g1[e] = g.w; g2[e] = g.s; g3[e] = g.m; }
           }
-          lprod[k] = c.A.val[b.k0 + k] * uv;
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const int k = threadIdx.x + e * TB;
+          if (k < cn) {
+            double uv;
+            if (pre) uv = g0[e];
+            else {
+              const double sj = first ? g1[e] : (g1[e] + beta * g2[e]);
+              uv = g3[e] * (g0[e] - alpha * sj);
+            }
+            lprod[k] = eval[e] * uv;
+          }
         }
       }
       __syncthreads();
@@ -583,7 +664,7 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
         int a0, a1;
         if (bi == (int)blockIdx.x && i == b.r0 + rg) { a0 = rp0; a1 = rp1; }
         else { a0 = c.A.rowptr[i]; a1 = c.A.rowptr[i + 1]; }
-        const double acc = row_sum_par<RL>(lprod, a0 - b.k0, a1 - b.k0, rlane);
+        const double acc = row_sum_par(lprod, a0 - b.k0, a1 - b.k0, rlane, RL);
         if (rlane == 0) t[i] = c.rho[i] * acc;
       }
     }
@@ -591,7 +672,6 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   }
 }
 
-template <int RL>
 __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   if (flags & 64) return;                                                            // timing probe: empty kernel
   State *st = c.st;
@@ -602,9 +682,10 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   RowBlk b = {0, 0, 0, 0};
   if (has_blk) b = c.M.blk[blockIdx.x];
   const int cnt = b.k1 - b.k0;
-  const bool small = has_blk && cnt <= MAX_CHUNK;
+  const bool small = has_blk && !IS_LONG(b);
   double ev[EPT];
-  const int rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
+  int RL = lanes_for(b.r1 - b.r0);
+  int rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
   int rp0 = 0, rp1 = 0;
   if (small) {
     if (b.r0 + rg < b.r1) { rp0 = c.M.rowptr[b.r0 + rg]; rp1 = c.M.rowptr[b.r0 + rg + 1]; }
@@ -621,19 +702,19 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
     }
   }
   if (!bench && (!run || done)) return;
-  if (flags & 16) { if (ev[0] == 12345.678 && run == 77) c.w[0] = ev[1]; return; }   // timing probe: launch + prefetch only
+  if (flags & 16) { if (ev[0] == 12345.678 && run == 77) c.kp[0] = ev[1]; return; }   // timing probe: launch + prefetch only
   LDS_DECL(1);
-  const double *r = c.r2 + (it & 1) * c.n;
+  G4 *gc = c.g4 + (size_t)(it & 1) * c.n;
   double pg = 0, pd = 0, prr = 0;
   for (int bi = blockIdx.x; bi < c.M.nblk; bi += gridDim.x) {
-    if (bi != (int)blockIdx.x) b = c.M.blk[bi];
+    if (bi != (int)blockIdx.x) { b = c.M.blk[bi]; RL = lanes_for(b.r1 - b.r0); rg = threadIdx.x / RL; rlane = threadIdx.x % RL; }
     const int cn = b.k1 - b.k0;
-    if (cn > MAX_CHUNK) {
+    if (IS_LONG(b)) {
       const double acc = long_row_dot(c.M, b.k0, b.k1, c.ut, red);
       if (threadIdx.x == 0) {
         const int j = b.r0;
-        const double uj = c.ut[j], wj = acc + sigma * uj, rj = r[j];
-        c.w[j] = wj; pg += rj * uj; pd += wj * uj; prr += rj * rj;
+        const double uj = c.ut[j], wj = acc + sigma * uj, rj = gc[j].r;
+        gc[j].w = wj; pg += rj * uj; pd += wj * uj; prr += rj * rj;
       }
     } else {
       if (bi == (int)blockIdx.x) {
@@ -645,17 +726,17 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
         int a0, a1;
         if (bi == (int)blockIdx.x && j == b.r0 + rg) { a0 = rp0; a1 = rp1; }
         else { a0 = c.M.rowptr[j]; a1 = c.M.rowptr[j + 1]; }
-        const double acc = row_sum_par<RL>(lprod, a0 - b.k0, a1 - b.k0, rlane);
+        const double acc = row_sum_par(lprod, a0 - b.k0, a1 - b.k0, rlane, RL);
         if (rlane == 0) {
-          const double uj = c.ut[j], wj = acc + sigma * uj, rj = r[j];
-          c.w[j] = wj;
+          const double uj = c.ut[j], wj = acc + sigma * uj, rj = gc[j].r;
+          gc[j].w = wj;
           pg += rj * uj; pd += wj * uj; prr += rj * rj;
         }
       }
     }
     __syncthreads();
   }
-  if (flags & 32) { if (pg == 12345.678) c.w[0] = pd + prr; return; }                // timing probe: no block reductions
+  if (flags & 32) { if (pg == 12345.678) c.kp[0] = pd + prr; return; }                // timing probe: no block reductions
   block_sum3(pg, pd, prr, red);
   if (threadIdx.x == 0) { c.part_gam[blockIdx.x] = pg; c.part_del[blockIdx.x] = pd; c.part_rr[blockIdx.x] = prr; }
 }
@@ -670,7 +751,8 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
   LDS_DECL(1);
   const Params prm = *c.prm;
   double rr[1];
-  reduce_parts<1>(c.part_rr, nullptr, nullptr, c.gridM, red, rr);
+  if (c.big) rr[0] = c.redout[0];
+  else reduce_parts<1>(c.part_rr, nullptr, nullptr, c.gridM, red, rr);
   const int iters = st->iters[0] > st->iters[1] ? st->iters[0] : st->iters[1];
   const bool conv = st->done == 1 || rr[0] <= st->tol2;
   const bool force = st->done == 2 || iters >= prm.pcg_max_iter || st->neg_curv;
@@ -697,7 +779,7 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
   }
   for (int bi = blockIdx.x; bi < c.A.nblk; bi += gridDim.x) {
     const RowBlk b = c.A.blk[bi];
-    const bool longrow = (b.k1 - b.k0) > MAX_CHUNK;
+    const bool longrow = IS_LONG(b);
     if (!longrow) {
       stage_products<1>(c.A, b, c.va, nullptr, lprod, nullptr);
       __syncthreads();
@@ -735,6 +817,7 @@ __global__ void __launch_bounds__(TB) k_precond(Ctx c) {
       s += c.rho[c.M.col[k] - c.n] * a * a;
     }
     c.minv[j] = 1.0 / s;
+    c.g4[j].m = 1.0 / s; c.g4[c.n + j].m = 1.0 / s;
   }
 }
 
@@ -755,7 +838,7 @@ __global__ void __launch_bounds__(TB) k_spmv(DevMat Mx, const double *in, double
   LDS_DECL(1);
   for (int bi = blockIdx.x; bi < Mx.nblk; bi += gridDim.x) {
     const RowBlk b = Mx.blk[bi];
-    if ((b.k1 - b.k0) > MAX_CHUNK) {
+    if (IS_LONG(b)) {
       int ka = b.k0, kb = b.k1;
       if (sel == 1) kb = Mx.split[b.r0];
       if (sel == 2) ka = Mx.split[b.r0];
@@ -788,7 +871,7 @@ __global__ void __launch_bounds__(TB) k_residuals(Ctx c) {
     double m_pu = 0, m_ps = 0, m_zu = 0, m_zs = 0, m_au = 0, m_as = 0, m_du = 0, m_ds = 0, lhs = 0;
     for (int bi = blockIdx.x; bi < c.A.nblk; bi += c.gridA) {
       const RowBlk b = c.A.blk[bi];
-      const bool longrow = (b.k1 - b.k0) > MAX_CHUNK;
+      const bool longrow = IS_LONG(b);
       if (!longrow) { stage_products<1>(c.A, b, x, nullptr, lprod, nullptr); __syncthreads(); }
       for (int i = b.r0 + (longrow ? 0 : threadIdx.x); i < b.r1; i += (longrow ? 1 : TB)) {
         double ax;
@@ -825,7 +908,7 @@ __global__ void __launch_bounds__(TB) k_residuals(Ctx c) {
   double m_xu = 0, m_xs = 0, obj = 0, qdx = 0;
   for (int bi = bid; bi < c.M.nblk; bi += c.gridM) {
     const RowBlk b = c.M.blk[bi];
-    const bool longrow = (b.k1 - b.k0) > MAX_CHUNK;
+    const bool longrow = IS_LONG(b);
     if (!longrow) { stage_products<1>(c.M, b, c.xy, nullptr, lprod, nullptr); __syncthreads(); }
     for (int j = b.r0 + (longrow ? 0 : threadIdx.x); j < b.r1; j += (longrow ? 1 : TB)) {
       double px, aty;
@@ -883,7 +966,7 @@ __global__ void __launch_bounds__(TB) k_certificates(Ctx c, double eps_dx, int u
     double viol = 0;
     for (int bi = blockIdx.x; bi < c.A.nblk; bi += c.gridA) {
       const RowBlk b = c.A.blk[bi];
-      const bool longrow = (b.k1 - b.k0) > MAX_CHUNK;
+      const bool longrow = IS_LONG(b);
       if (!longrow) { stage_products<1>(c.A, b, c.dxy, nullptr, lprod, nullptr); __syncthreads(); }
       for (int i = b.r0 + (longrow ? 0 : threadIdx.x); i < b.r1; i += (longrow ? 1 : TB)) {
         double adx;
@@ -904,7 +987,7 @@ __global__ void __launch_bounds__(TB) k_certificates(Ctx c, double eps_dx, int u
   double m_tu = 0, m_ts = 0, m_pu = 0, m_ps = 0;
   for (int bi = bid; bi < c.M.nblk; bi += c.gridM) {
     const RowBlk b = c.M.blk[bi];
-    const bool longrow = (b.k1 - b.k0) > MAX_CHUNK;
+    const bool longrow = IS_LONG(b);
     if (!longrow) { stage_products<1>(c.M, b, c.dxy, nullptr, lprod, nullptr); __syncthreads(); }
     for (int j = b.r0 + (longrow ? 0 : threadIdx.x); j < b.r1; j += (longrow ? 1 : TB)) {
       double pdx, atdy;
@@ -957,6 +1040,7 @@ struct hipeng {
   std::map<int, hipGraphExec_t> graphs, cgraphs;
   int K = 8;
   int variant = 1;
+  bool split = false;     // large A: vector update and operator apply as two launches (plain 8-byte gathers)
   int rlA = 8, rlM = 8;   // lanes per row segment in the PCG kernels
   bool calibrated = false;
   hipeng_stats stats{};
@@ -981,9 +1065,15 @@ static void build_blocks(HostMat &H, int chunk) {
   H.blk.clear();
   int r = 0;
   while (r < H.nrows) {
-    int r1 = r + 1;
     const int k0 = H.rowptr[r];
-    while (r1 < H.nrows && H.rowptr[r1 + 1] - k0 <= chunk && (r1 - r) < 8 * TB) r1++;
+    if (H.rowptr[r + 1] - k0 >= LONG_ROW) {          // long row: a block of its own
+      H.blk.push_back({r, r + 1, k0, H.rowptr[r + 1]});
+      r++;
+      continue;
+    }
+    int r1 = r + 1;
+    while (r1 < H.nrows && H.rowptr[r1 + 1] - H.rowptr[r1] < LONG_ROW &&
+           H.rowptr[r1 + 1] - k0 <= chunk && (r1 - r) < 8 * TB) r1++;
     H.blk.push_back({r, r1, k0, H.rowptr[r1]});
     r = r1;
   }
@@ -1139,30 +1229,38 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
     return rl;
   };
   e->rlA = pick_rl(e->A); e->rlM = pick_rl(e->M);
+  e->split = false;   // experimental (OSQP_AMD_SPLIT=1): not faster on config 3 in round 1
+  if (const char *sp = getenv("OSQP_AMD_SPLIT")) e->split = atoi(sp) != 0;
   if (upload_mat(e, e->A) || upload_mat(e, e->M)) return HIPENG_ERR_HIP;
   Ctx &c = e->c;
   c.n = n; c.m = m;
   c.A = dev_view(e->A); c.M = dev_view(e->M);
-  c.gridM = std::min(MAX_PARTS, std::max(1, c.M.nblk));
-  c.gridA = std::min(MAX_PARTS, std::max(std::max(1, c.A.nblk), std::min(elem_grid(n), 256)));
+  {
+    const char *v = getenv("OSQP_AMD_PCG_VARIANT");
+    e->variant = v ? atoi(v) : 1;          // 1 = Chronopoulos-Gear (2 kernels / iteration), 0 = classic (3)
+  }
+  c.big = 0;   // experimental (OSQP_AMD_BIG=1): measured slower than the capped grid on config 3
+  if (const char *bg = getenv("OSQP_AMD_BIG")) c.big = (atoi(bg) != 0 && e->variant == 1) ? 1 : 0;
+  const int cap = c.big ? BIG_GRID : MAX_PARTS;
+  c.gridM = std::min(cap, std::max(1, c.M.nblk));
+  c.gridA = std::min(cap, std::max(std::max(1, c.A.nblk), std::min(elem_grid(n), 256)));
 #define DA(field, cnt) if (dev_alloc(e, &c.field, (size_t)(cnt))) return HIPENG_ERR_HIP
   DA(xy, n + m); DA(z, m); DA(zt, m); DA(va, n + m); DA(vb, n + m);
   DA(q, n); DA(l, m); DA(u, m); DA(rho, m); DA(rhoinv, m); DA(minv, n); DA(pdiag, n);
   DA(r, n); DA(zz, n); DA(kp, n); DA(pt0, n + m); DA(pt1, n + m);
   DA(dxy, n + m); DA(dy, m); DA(cvec, n);
-  DA(r2, 2 * n); DA(s2, 2 * n); DA(pdir, n); DA(ut, n + m); DA(w, n);
+  DA(pdir, n); DA(ut, n + m); DA(g4, 2 * n);
   DA(D, n); DA(Dinv, n); DA(E, m); DA(Einv, m);
   const int np = std::max(c.gridM, c.gridA);
   DA(part_rz, np); DA(part_rr, np); DA(part_bb, np); DA(part_pkp, np);
   DA(part_s0, np); DA(part_s1, np); DA(part_s2, np); DA(part_gam, np); DA(part_del, np);
   DA(scal, SC_COUNT * 16);
+  DA(redout, 8);
   DA(st, 1);
 #undef DA
   {
-    const char *v = getenv("OSQP_AMD_PCG_VARIANT");
-    e->variant = v ? atoi(v) : 1;          // 1 = Chronopoulos-Gear (2 kernels / iteration), 0 = classic (3)
-    if (e->variant == 1) { c.init_r = c.r2 + n; c.init_z = c.ut; }
-    else { c.init_r = c.r; c.init_z = c.zz; }
+    if (e->variant == 1) { c.init_r = &c.g4[n].r; c.init_stride = 4; c.init_z = c.ut; }
+    else { c.init_r = c.r; c.init_stride = 1; c.init_z = c.zz; }
   }
   if (dev_alloc(e, &e->d_prm, 1)) return HIPENG_ERR_HIP;
   c.prm = e->d_prm;
@@ -1341,28 +1439,18 @@ extern "C" int hipeng_set_z(hipeng *e, const c_float *z) {
 
 // ---- graphs ---------------------------------------------------------------
 static void launch_cg_A(hipeng *e, int it, int flags) {
-  const Ctx &c = e->c;
-  switch (e->rlA) {
-  case 1: hipLaunchKernelGGL(k_cg_A<1>, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, flags); break;
-  case 2: hipLaunchKernelGGL(k_cg_A<2>, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, flags); break;
-  case 4: hipLaunchKernelGGL(k_cg_A<4>, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, flags); break;
-  default: hipLaunchKernelGGL(k_cg_A<8>, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, flags); break;
-  }
+  hipLaunchKernelGGL(k_cg_A, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, it, flags);
 }
 static void launch_cg_B(hipeng *e, int it, int flags) {
-  const Ctx &c = e->c;
-  switch (e->rlM) {
-  case 1: hipLaunchKernelGGL(k_cg_B<1>, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags); break;
-  case 2: hipLaunchKernelGGL(k_cg_B<2>, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags); break;
-  case 4: hipLaunchKernelGGL(k_cg_B<4>, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags); break;
-  default: hipLaunchKernelGGL(k_cg_B<8>, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags); break;
-  }
+  hipLaunchKernelGGL(k_cg_B, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
+  if (e->c.big) hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(1024), 0, e->stream, e->c);
 }
 
 static void launch_pcg_iter(hipeng *e, int it, int flags) {
   const Ctx &c = e->c;
   if (e->variant == 1) {
-    launch_cg_A(e, it, flags & ~1);
+    if (e->split) { launch_cg_A(e, it, (flags & ~1) | 16); launch_cg_A(e, it, (flags & 4) | 32); }
+    else launch_cg_A(e, it, flags & ~1);
     launch_cg_B(e, it, flags & 4);
     return;
   }
@@ -1380,6 +1468,7 @@ static int get_graph(hipeng *e, int K, bool cont, hipGraphExec_t *out) {
   HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
   if (!cont) {
     hipLaunchKernelGGL(k_pcg_init, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c);
+    if (e->c.big) hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(1024), 0, e->stream, e->c);
     if (e->variant == 1) {   // operator apply on u0 (+ first convergence test), then w0 and the first dots
       launch_cg_A(e, -1, 8);
       launch_cg_B(e, -1, 0);
@@ -1574,24 +1663,36 @@ extern "C" int hipeng_spmv(hipeng *e, int which, const c_float *x, c_float *y) {
 extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) {
   const int dbg = (which >> 8) & 0xff;
   which &= 0xff;
-  if (!e || !usec || reps <= 0 || which < 0 || which > 2) return HIPENG_ERR_ARG;
+  if (!e || !usec || reps <= 0 || which < 0 || which > 4) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   const Ctx &c = e->c;
   auto one = [&](int it) {
     if (e->variant == 1) {
       if (which == 0) launch_cg_A(e, it, 4);
+      else if (which == 3) launch_cg_A(e, it, 4 | 16);
+      else if (which == 4) launch_cg_A(e, it, 4 | 32);
       else launch_cg_B(e, it, 4 | dbg);
     } else if (which == 0) hipLaunchKernelGGL(k_pcg_Ap, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, 4);
     else if (which == 1) hipLaunchKernelGGL(k_pcg_Kp, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, 4);
     else hipLaunchKernelGGL(k_pcg_update, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, 4);
   };
-  for (int i = 0; i < 10; i++) one(i);
-  HIPCHK(hipEventRecord(e->ev0, e->stream));
+  // the launches are captured into one graph so the measurement is not bound by
+  // the host's eager launch rate (~3-4 us per launch)
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
   for (int i = 0; i < reps; i++) one(i);
+  HIPCHK(hipStreamEndCapture(e->stream, &g));
+  HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  HIPCHK(hipGraphDestroy(g));
+  HIPCHK(hipGraphLaunch(ge, e->stream));            // warm-up replay
+  HIPCHK(hipEventRecord(e->ev0, e->stream));
+  HIPCHK(hipGraphLaunch(ge, e->stream));
   HIPCHK(hipEventRecord(e->ev1, e->stream));
   HIPCHK(hipEventSynchronize(e->ev1));
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  HIPCHK(hipGraphExecDestroy(ge));
   *usec = 1e3 * (double)ms / reps;
   return 0;
 }

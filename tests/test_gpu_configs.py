@@ -1,0 +1,122 @@
+"""GPU parity on the remaining BASELINE configs: 3 (Lasso-as-QP, update_matrices +
+warm-start path) and 5 (portfolio, block-diagonal dense P), at sizes the oracle
+finishes in seconds, plus size-independent KKT properties at full size."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+def _kkt(pb, r):
+    P = pb["P"] + sparse.triu(pb["P"], 1).T
+    A = pb["A"]
+    l = np.maximum(pb["l"], -1e30); u = np.minimum(pb["u"], 1e30)
+    Ax = A @ r.x
+    pri = np.abs(Ax - np.clip(Ax, l, u)).max()
+    dua = np.abs(P @ r.x + pb["q"] + A.T @ r.y).max()
+    pscale = max(np.abs(Ax).max(), 1e-12)
+    dscale = max(np.abs(P @ r.x).max(), np.abs(A.T @ r.y).max(), np.abs(pb["q"]).max())
+    return pri, dua, pscale, dscale
+
+
+# These two families are equality-heavy (rho_eq = 1e3 rho): the reduced matrix has a
+# condition number of 1e5..1e6, and a residual-based PCG stop at eps_rel carries a forward
+# error of about cond * eps_rel.  Stated tolerances: at the default eps_rel = 1e-10
+# x, y <= 1e-5 relative, objective <= 1e-6; at eps_rel = 1e-12 the usual 1e-6 / 1e-8.
+TOLS = [(1e-10, 1e-5, 1e-6), (1e-12, 1e-6, 1e-8)]
+
+
+@pytest.fixture(params=TOLS, ids=["pcg1e-10", "pcg1e-12"])
+def pcg_tol(request):
+    import osqp_amd
+    eps, txy, tobj = request.param
+    old = osqp_amd.engine_options()["pcg_eps_rel"]
+    osqp_amd.set_engine_options(pcg_eps_rel=eps)
+    yield txy, tobj
+    osqp_amd.set_engine_options(pcg_eps_rel=old)
+
+
+def test_lasso_small_matches_oracle_with_updates(gpu_lib, oracle_mod, pcg_tol):
+    """Config 3 shape at n_feat=200, m_data=400: solve, gamma sweep through
+    osqp_update_lin_cost, then osqp_update_A with perturbed data and a warm-started
+    re-solve (docs/examples/lasso.rst:41-63; src/osqp.c:1092-1169)."""
+    import osqp_amd
+    txy, tobj = pcg_tol
+    from osqp_amd.problems import lasso_qp
+    pb = lasso_qp(200, 400, density=0.15, seed=2)
+    data = {k: pb[k] for k in "PqAlu"}
+    kw = dict(eps_abs=1e-4, eps_rel=1e-4, adaptive_rho_interval=50)
+    sg = osqp_amd.OSQP().setup(**data, **kw); so = oracle_mod.OracleOSQP().setup(**data, **kw)
+    nf, md = pb["n_feat"], pb["m_data"]
+    for gamma in (1.0, 3.0):
+        q = np.concatenate([np.zeros(nf + md), gamma * np.ones(nf)])
+        sg.update(q=q); so.update(q=q)
+        rg, ro = sg.solve(), so.solve()
+        assert rg.info.status == ro.info.status == "solved"
+        assert rg.info.iter == ro.info.iter and rg.info.rho_updates == ro.info.rho_updates
+        assert _rel(rg.x, ro.x) < txy and _rel(rg.y, ro.y) < txy
+        assert abs(rg.info.obj_val - ro.info.obj_val) <= tobj * max(1.0, abs(ro.info.obj_val))
+    A = sparse.csc_matrix(pb["A"]); A.sort_indices()
+    rng = np.random.default_rng(5)
+    Ax_new = A.data * (1.0 + 0.01 * rng.standard_normal(A.nnz))
+    assert sg.update(Ax=Ax_new) == 0 and so.update(Ax=Ax_new) == 0
+    rg, ro = sg.solve(), so.solve()
+    assert rg.info.status == ro.info.status == "solved" and rg.info.iter == ro.info.iter
+    assert _rel(rg.x, ro.x) < txy and _rel(rg.y, ro.y) < txy
+
+
+def test_portfolio_small_matches_oracle(gpu_lib, oracle_mod, pcg_tol):
+    """Config 5 shape at 8 dense blocks of 25 plus sparse sector rows; the budget row
+    (all ones) is a dense row that takes the long-row kernels' path at larger n."""
+    import osqp_amd
+    from osqp_amd.problems import portfolio_qp
+    txy, tobj = pcg_tol
+    pb = portfolio_qp(8, 25, sector_rows=5, seed=3)
+    kw = dict(eps_abs=1e-5, eps_rel=1e-5)
+    rg = osqp_amd.OSQP().setup(**pb, **kw).solve(); ro = oracle_mod.OracleOSQP().setup(**pb, **kw).solve()
+    assert rg.info.status == ro.info.status == "solved"
+    assert rg.info.iter == ro.info.iter and rg.info.rho_updates == ro.info.rho_updates
+    assert _rel(rg.x, ro.x) < txy and _rel(rg.y, ro.y) < txy
+    assert abs(rg.info.obj_val - ro.info.obj_val) <= tobj * max(1.0, abs(ro.info.obj_val))
+
+
+def test_portfolio_full_size_properties(gpu_lib):
+    """Config 5 at full size (n=50000: 400 dense 125x125 blocks, budget row with 50000
+    entries): KKT residuals of the returned point below the requested tolerances."""
+    import osqp_amd
+    from osqp_amd.problems import portfolio_qp
+    pb = portfolio_qp()
+    eps = 1e-4
+    s = osqp_amd.OSQP().setup(**pb, eps_abs=eps, eps_rel=eps)
+    r = s.solve()
+    assert r.info.status == "solved"
+    pri, dua, ps, ds = _kkt(pb, r)
+    assert pri <= eps + eps * ps + 1e-9 and dua <= eps + eps * ds + 1e-9
+    assert abs(r.x.sum() - 1.0) < 1e-3 and r.x.min() > -1e-3     # budget and long-only
+    assert s.stats()["pcg_forced"] == 0
+
+
+def test_lasso_mid_size_properties(gpu_lib):
+    """Config 3 at n_feat=1000, m_data=2000 (rows of 300 and columns of 300+ entries):
+    KKT residuals + warm start after update_A needs fewer iterations than a cold one."""
+    import osqp_amd
+    from osqp_amd.problems import lasso_qp
+    pb = lasso_qp(1000, 2000, density=0.15, seed=1)
+    data = {k: pb[k] for k in "PqAlu"}
+    eps = 1e-4
+    s = osqp_amd.OSQP().setup(**data, eps_abs=eps, eps_rel=eps)
+    r = s.solve()
+    assert r.info.status == "solved"
+    pri, dua, ps, ds = _kkt(data, r)
+    assert pri <= eps + eps * ps + 1e-9 and dua <= eps + eps * ds + 1e-9
+    cold_iters = r.info.iter
+    A = sparse.csc_matrix(pb["A"]); A.sort_indices()
+    Ax_new = A.data * (1.0 + 1e-4 * np.random.default_rng(0).standard_normal(A.nnz))
+    assert s.update(Ax=Ax_new) == 0
+    r2 = s.solve()
+    assert r2.info.status == "solved" and r2.info.iter <= cold_iters
