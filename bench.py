@@ -64,8 +64,20 @@ def kernel_roofline(solver, reps=300):
         rows.append(dict(kernel=names[which], usec=us.value, bytes=by.value,
                          gbs=by.value / (us.value * 1e-6) / 1e9))
     dom = max(rows, key=lambda r: r["usec"])
+    # HBM-side traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    # --pmc WRITE_SIZE, separate runs; profiles/r01_*_pmc_and_durations.json), same workload only
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_and_durations.json")))
+        if (solver.n, solver.m) == (10000, 20000):
+            k = [v for kk, v in prof["kernels"].items() if kk.startswith(dom["kernel"])][0]
+            traffic = round(1024.0 * (k["FETCH_SIZE_KB"]["median"] + k["WRITE_SIZE_KB"]["median"]), 1)
+    except Exception:
+        traffic = None
     return dict(bound="hbm", achieved=round(dom["gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(dom["gbs"] / HBM_PEAK_GBS, 5), traffic=None, kernel=dom["kernel"],
+                frac=round(dom["gbs"] / HBM_PEAK_GBS, 5), traffic=traffic, kernel=dom["kernel"],
+                traffic_note="bytes/launch = FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes, "
+                             "uncorrected (4/8-byte-per-lane loads are outside the guide's calibrated 16 B pattern)",
                 bytes_per_launch=dom["bytes"], usec_per_launch=round(dom["usec"], 3),
                 note="launch-to-launch period of %d graph-captured back-to-back launches (includes the "
                      "dependent-kernel boundary); the 8 MB working set is L2/Infinity-Cache resident" % reps,

@@ -90,19 +90,25 @@ __device__ __forceinline__ double b_wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
   return v;
 }
+template <int NW>
 __device__ __forceinline__ double b_sum(double v, double *red) {
   v = b_wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  double t = (red[0] + red[1]) + (red[2] + red[3]);
+  if (NW == 8) t += (red[4] + red[5]) + (red[6] + red[7]);
+  return t;
 }
+template <int NW>
 __device__ __forceinline__ double b_max(double v, double *red) {
   v = b_wave_max(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return fmax(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])), fmax(fmax(red[4], red[5]), fmax(red[6], red[7])));
+  double t = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (NW == 8) t = fmax(t, fmax(fmax(red[4], red[5]), fmax(red[6], red[7])));
+  return t;
 }
 __device__ __forceinline__ double clip_scale(double v) {
   if (v < 1e-4) v = 1.0;
@@ -167,9 +173,9 @@ __device__ __forceinline__ double p_row_dot(const BL &s, const double *v, int j)
 // register-tiled K^-1: thread (tr, tc) of a 16 x 16 grid owns rows tr*T.. and
 // columns tc*T.. of the (padded) NP x NP matrix, NP = 16*T.
 // ---------------------------------------------------------------------------
-template <int TR, int TC>
+template <int TR, int TC, int GC>
 __device__ __forceinline__ void form_K(double (&a)[TR][TC], int n, const BL &s, double sigma) {
-  const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
+  const int tr = threadIdx.x / GC, tc = threadIdx.x % GC;
   const double *rho = s_rho;
 #pragma unroll 1
   for (int r = 0; r < TR; ++r) {
@@ -204,7 +210,7 @@ __device__ __forceinline__ void form_K(double (&a)[TR][TC], int n, const BL &s, 
 
 // In-place Gauss-Jordan inversion without pivoting (K is SPD).  One barrier per
 // pivot: the pivot row / column are exchanged through double-buffered LDS.
-template <int TR, int TC>
+template <int TR, int TC, int GC>
 __device__ __forceinline__ void invert_tiles(double (&a)[TR][TC], const BL &s, int n) {
   // The pivot loop is unrolled by TR (a multiple of TC) so that the pivot's
   // position inside a tile (ko, kco) is a compile-time constant: the register
@@ -213,7 +219,7 @@ __device__ __forceinline__ void invert_tiles(double (&a)[TR][TC], const BL &s, i
   // row k / column k overwrite their strip with the Gauss-Jordan special cases.
   static_assert(TR % TC == 0, "tile shape");
   constexpr int NP = 16 * TR;
-  const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
+  const int tr = threadIdx.x / GC, tc = threadIdx.x % GC;
   const int nkb = (n + TR - 1) / TR;    // padded rows/columns are identity: nothing to eliminate
 #pragma unroll 1
   for (int kb = 0; kb < nkb; ++kb) {
@@ -225,17 +231,17 @@ __device__ __forceinline__ void invert_tiles(double (&a)[TR][TC], const BL &s, i
       double *rowk = s.rowk + (k & 1) * NP, *colk = s.colk + (k & 1) * NP;
       if (tr == kb) {
 #pragma unroll
-        for (int c = 0; c < TC; ++c) rowk[c * 32 + tc] = a[ko][c];   // [c][tc]: lane stride 8 B
+        for (int c = 0; c < TC; ++c) rowk[c * GC + tc] = a[ko][c];   // [c][tc]: lane stride 8 B
       }
       if (tc == kc) {
 #pragma unroll
         for (int r = 0; r < TR; ++r) colk[tr * TR + r] = a[r][kco];
       }
       __syncthreads();
-      const double piv = 1.0 / rowk[kco * 32 + kc];
+      const double piv = 1.0 / rowk[kco * GC + kc];
       double rk[TC];
 #pragma unroll
-      for (int c = 0; c < TC; ++c) rk[c] = rowk[c * 32 + tc] * piv;
+      for (int c = 0; c < TC; ++c) rk[c] = rowk[c * GC + tc] * piv;
 #pragma unroll
       for (int r = 0; r < TR; ++r) {
         const double ci = colk[tr * TR + r];
@@ -256,15 +262,15 @@ __device__ __forceinline__ void invert_tiles(double (&a)[TR][TC], const BL &s, i
 }
 
 // out_i = sum_j Kinv_ij in_j ; in / out are LDS vectors of length >= NP
-template <int TR, int TC>
+template <int TR, int TC, int GC>
 __device__ __forceinline__ void tile_gemv(const double (&a)[TR][TC], const double *in, double *out,
                                           double *gp) {
-  // partial sums of each thread's tile go through LDS (gp: NP rows x 33 doubles,
+  // partial sums of each thread's tile go through LDS (gp: NP rows x (GC+1) doubles,
   // one padding word per row => conflict-free writes and reads) and are added in
   // ascending column-block order by the first NP threads: fixed order, no
   // cross-lane shuffles.
   constexpr int NP = 16 * TR;
-  const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
+  const int tr = threadIdx.x / GC, tc = threadIdx.x % GC;
   double bj[TC];
 #pragma unroll
   for (int c = 0; c < TC; ++c) bj[c] = in[tc * TC + c];
@@ -273,13 +279,13 @@ __device__ __forceinline__ void tile_gemv(const double (&a)[TR][TC], const doubl
     double v = 0.0;
 #pragma unroll
     for (int c = 0; c < TC; ++c) v = __builtin_fma(a[r][c], bj[c], v);
-    gp[(tr * TR + r) * 33 + tc] = v;
+    gp[(tr * TR + r) * (GC + 1) + tc] = v;
   }
   __syncthreads();
   if (threadIdx.x < NP) {
     double v = 0.0;
 #pragma unroll 8
-    for (int t = 0; t < 32; ++t) v += gp[threadIdx.x * 33 + t];
+    for (int t = 0; t < GC; ++t) v += gp[threadIdx.x * (GC + 1) + t];
     out[threadIdx.x] = v;
   }
   __syncthreads();
@@ -288,9 +294,10 @@ __device__ __forceinline__ void tile_gemv(const double (&a)[TR][TC], const doubl
 // ---------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------
-template <int TR, int TC>
-__global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BIO io, int phase) {
-  constexpr int NP = 16 * TR;
+template <int TR, int TC, int GC>
+__global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSettings st, BIO io, int phase) {
+  constexpr int NP = 16 * TR, NT = 16 * GC, NW = NT / 64;
+  static_assert(GC * TC == NP, "tile shape");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int n = p.n, m = p.m, tid = threadIdx.x;
   const long long qp = blockIdx.x;
@@ -300,7 +307,7 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
     s.NP = NP; s.m = m;
     s.Pv = w; w += p.nnzP; s.Av = w; w += p.nnzA;
     s.nv = w; w += 7 * NP; s.mv = w; w += 11 * m;
-    s.rowk = w; w += 2 * NP; s.colk = w; w += 2 * NP; s.red = w; w += 32; s.gp = w; w += 33 * NP;
+    s.rowk = w; w += 2 * NP; s.colk = w; w += 2 * NP; s.red = w; w += 64; s.gp = w; w += (GC + 1) * NP;
     int *iw = reinterpret_cast<int *>(w);
     s.ctype = iw; iw += m;
     int *ib = iw;
@@ -310,7 +317,7 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
     s.Rp = iw; iw += m + 1; s.Rj = iw; iw += p.nnzA; s.Rk = iw; iw += p.nnzA;
     // the host packs the twelve index arrays back to back in this order
     const int tot = (int)(iw - ib);
-    for (int k = tid; k < tot; k += BT) ib[k] = p.packed[k];
+    for (int k = tid; k < tot; k += NT) ib[k] = p.packed[k];
   }
   double a[TR][TC];
   unsigned long long tstamp[8];
@@ -319,24 +326,24 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
 
   // ---- load: raw problem (setup phase) or the per-QP workspace (solve phase) ---
   double cs = 1.0;   // cost scaling c
-  for (int j = tid; j < NP; j += BT) {
+  for (int j = tid; j < NP; j += NT) {
     s_q[j] = 0.0; s_x[j] = 0.0; s_xt[j] = 0.0; s_dx[j] = 0.0; s_D[j] = 1.0; s_tn[j] = 0.0; s_b[j] = 0.0;
   }
-  for (int i = tid; i < m; i += BT) { s_z[i] = 0.0; s_y[i] = 0.0; s_E[i] = 1.0; s_dy[i] = 0.0; s_zt[i] = 0.0; }
+  for (int i = tid; i < m; i += NT) { s_z[i] = 0.0; s_y[i] = 0.0; s_E[i] = 1.0; s_dy[i] = 0.0; s_zt[i] = 0.0; }
   __syncthreads();
   const long long nv_ = (long long)p.nnzP + p.nnzA;
   if (phase == 0) {
     const double *Pg = io.Px + qp * io.strideP, *Ag = io.Ax + qp * io.strideA;
-    for (int k = tid; k < p.nnzP; k += BT) s.Pv[k] = Pg[k];
-    for (int k = tid; k < p.nnzA; k += BT) s.Av[k] = Ag[k];
-    for (int j = tid; j < n; j += BT) s_q[j] = io.Q[qp * n + j];
-    for (int i = tid; i < m; i += BT) { s_l[i] = io.L[qp * m + i]; s_u[i] = io.U[qp * m + i]; }
+    for (int k = tid; k < p.nnzP; k += NT) s.Pv[k] = Pg[k];
+    for (int k = tid; k < p.nnzA; k += NT) s.Av[k] = Ag[k];
+    for (int j = tid; j < n; j += NT) s_q[j] = io.Q[qp * n + j];
+    for (int i = tid; i < m; i += NT) { s_l[i] = io.L[qp * m + i]; s_u[i] = io.U[qp * m + i]; }
   } else {
     const double *Wv = io.Wv + qp * nv_;
-    for (int k = tid; k < p.nnzP; k += BT) s.Pv[k] = Wv[k];
-    for (int k = tid; k < p.nnzA; k += BT) s.Av[k] = Wv[p.nnzP + k];
-    for (int j = tid; j < n; j += BT) { s_q[j] = io.Wq[qp * n + j]; s_D[j] = io.Wd[qp * n + j]; }
-    for (int i = tid; i < m; i += BT) {
+    for (int k = tid; k < p.nnzP; k += NT) s.Pv[k] = Wv[k];
+    for (int k = tid; k < p.nnzA; k += NT) s.Av[k] = Wv[p.nnzP + k];
+    for (int j = tid; j < n; j += NT) { s_q[j] = io.Wq[qp * n + j]; s_D[j] = io.Wd[qp * n + j]; }
+    for (int i = tid; i < m; i += NT) {
       s_l[i] = io.Wl[qp * m + i]; s_u[i] = io.Wu[qp * m + i]; s_E[i] = io.We[qp * m + i];
       s.ctype[i] = io.Wt[qp * m + i];
     }
@@ -347,52 +354,52 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
   tstamp[1] = wall_clock64();
   // ---- Ruiz equilibration (scaling.c:44-156), per QP -------------------------
   for (int pass = 0; phase == 0 && pass < st.scaling; ++pass) {
-    for (int j = tid; j < n; j += BT) {
+    for (int j = tid; j < n; j += NT) {
       double v = 0.0;
       for (int k = s.Fp[j]; k < s.Fp[j + 1]; ++k) v = fmax(v, fabs(s.Pv[s.Fk[k]]));
       for (int k = s.Ap[j]; k < s.Ap[j + 1]; ++k) v = fmax(v, fabs(s.Av[k]));
       s_tn[j] = 1.0 / sqrt(clip_scale(v));
     }
-    for (int i = tid; i < m; i += BT) {
+    for (int i = tid; i < m; i += NT) {
       double v = 0.0;
       for (int k = s.Rp[i]; k < s.Rp[i + 1]; ++k) v = fmax(v, fabs(s.Av[s.Rk[k]]));
       s_tm[i] = 1.0 / sqrt(clip_scale(v));
     }
     __syncthreads();
-    for (int k = tid; k < p.nnzP; k += BT) s.Pv[k] = (s.Pv[k] * s_tn[s.Pi[k]]) * s_tn[s.Pc[k]];
-    for (int k = tid; k < p.nnzA; k += BT) s.Av[k] = (s.Av[k] * s_tm[s.Ai[k]]) * s_tn[s.Ac[k]];
-    for (int j = tid; j < n; j += BT) { s_q[j] = s_q[j] * s_tn[j]; s_D[j] = s_tn[j] * s_D[j]; }
-    for (int i = tid; i < m; i += BT) s_E[i] = s_tm[i] * s_E[i];
+    for (int k = tid; k < p.nnzP; k += NT) s.Pv[k] = (s.Pv[k] * s_tn[s.Pi[k]]) * s_tn[s.Pc[k]];
+    for (int k = tid; k < p.nnzA; k += NT) s.Av[k] = (s.Av[k] * s_tm[s.Ai[k]]) * s_tn[s.Ac[k]];
+    for (int j = tid; j < n; j += NT) { s_q[j] = s_q[j] * s_tn[j]; s_D[j] = s_tn[j] * s_D[j]; }
+    for (int i = tid; i < m; i += NT) s_E[i] = s_tm[i] * s_E[i];
     __syncthreads();
     // cost normalisation: mean column norm of P (sequential sum, reference order) vs |q|_inf
     double cn = 0.0, qn = 0.0;
-    for (int j = tid; j < n; j += BT) {
+    for (int j = tid; j < n; j += NT) {
       double v = 0.0;
       for (int k = s.Fp[j]; k < s.Fp[j + 1]; ++k) v = fmax(v, fabs(s.Pv[s.Fk[k]]));
       s_tn[j] = v;
       qn = fmax(qn, fabs(s_q[j]));
     }
-    qn = b_max(qn, s.red);
-    if (tid == 0) { double acc = 0.0; for (int j = 0; j < n; ++j) acc += s_tn[j]; s.red[6] = acc / (double)n; }
+    qn = b_max<NW>(qn, s.red);
+    if (tid == 0) { double acc = 0.0; for (int j = 0; j < n; ++j) acc += s_tn[j]; s.red[12] = acc / (double)n; }
     __syncthreads();
-    cn = s.red[6];
+    cn = s.red[12];
     double ct = fmax(cn, clip_scale(qn));
     ct = 1.0 / clip_scale(ct);
-    for (int k = tid; k < p.nnzP; k += BT) s.Pv[k] *= ct;
-    for (int j = tid; j < n; j += BT) s_q[j] *= ct;
+    for (int k = tid; k < p.nnzP; k += NT) s.Pv[k] *= ct;
+    for (int j = tid; j < n; j += NT) s_q[j] *= ct;
     cs *= ct;
     __syncthreads();
   }
   const double cinv = 1.0 / cs;
   const bool unscaled = st.scaling && !st.scaled_termination;
-  if (phase == 0) { for (int i = tid; i < m; i += BT) { s_l[i] = s_l[i] * s_E[i]; s_u[i] = s_u[i] * s_E[i]; } }
+  if (phase == 0) { for (int i = tid; i < m; i += NT) { s_l[i] = s_l[i] * s_E[i]; s_u[i] = s_u[i] * s_E[i]; } }
   __syncthreads();
 
   tstamp[2] = wall_clock64();
   // ---- rho vector (auxil.c:76-98) and warm start -----------------------------
   double rho = phase == 0 ? st.rho : io.rho_io[qp];
   rho = fmin(fmax(rho, 1e-6), 1e6);
-  for (int i = tid; i < m; i += BT) {
+  for (int i = tid; i < m; i += NT) {
     int t = 0;
     if (phase == 0) {
       if (s_l[i] < -BINF && s_u[i] > BINF) t = -1;
@@ -403,40 +410,40 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
     s_rho[i] = r; s_rinv[i] = 1.0 / r;
   }
   if (st.warm_start && phase != 0) {
-    for (int j = tid; j < n; j += BT) s_x[j] = io.Xs[qp * n + j];
-    for (int i = tid; i < m; i += BT) { s_z[i] = io.Zs[qp * m + i]; s_y[i] = io.Ys[qp * m + i]; }
+    for (int j = tid; j < n; j += NT) s_x[j] = io.Xs[qp * n + j];
+    for (int i = tid; i < m; i += NT) { s_z[i] = io.Zs[qp * m + i]; s_y[i] = io.Ys[qp * m + i]; }
   }
   __syncthreads();
   tstamp[3] = wall_clock64();
   bool kinv_dirty = false;
   double *Wk = io.Wk + qp * (long long)(NP * NP);
   if (phase == 0 || io.flag[qp]) {
-    form_K<TR, TC>(a, n, s, st.sigma);
+    form_K<TR, TC, GC>(a, n, s, st.sigma);
     tstamp[4] = wall_clock64();
-    invert_tiles<TR, TC>(a, s, n);
+    invert_tiles<TR, TC, GC>(a, s, n);
     kinv_dirty = true;
   } else {
 #pragma unroll
     for (int r = 0; r < TR; ++r)
 #pragma unroll
-      for (int c = 0; c < TC; ++c) a[r][c] = Wk[(r * TC + c) * BT + tid];
+      for (int c = 0; c < TC; ++c) a[r][c] = Wk[(r * TC + c) * NT + tid];
     tstamp[4] = wall_clock64();
   }
   tstamp[5] = wall_clock64();
   if (phase == 0) {
     // ---- store the workspace and stop: the solve phase starts from here -------
     double *Wv = io.Wv + qp * nv_;
-    for (int k = tid; k < p.nnzP; k += BT) Wv[k] = s.Pv[k];
-    for (int k = tid; k < p.nnzA; k += BT) Wv[p.nnzP + k] = s.Av[k];
-    for (int j = tid; j < n; j += BT) { io.Wq[qp * n + j] = s_q[j]; io.Wd[qp * n + j] = s_D[j]; io.Xs[qp * n + j] = 0.0; }
-    for (int i = tid; i < m; i += BT) {
+    for (int k = tid; k < p.nnzP; k += NT) Wv[k] = s.Pv[k];
+    for (int k = tid; k < p.nnzA; k += NT) Wv[p.nnzP + k] = s.Av[k];
+    for (int j = tid; j < n; j += NT) { io.Wq[qp * n + j] = s_q[j]; io.Wd[qp * n + j] = s_D[j]; io.Xs[qp * n + j] = 0.0; }
+    for (int i = tid; i < m; i += NT) {
       io.Wl[qp * m + i] = s_l[i]; io.Wu[qp * m + i] = s_u[i]; io.We[qp * m + i] = s_E[i];
       io.Wt[qp * m + i] = s.ctype[i]; io.Zs[qp * m + i] = 0.0; io.Ys[qp * m + i] = 0.0;
     }
 #pragma unroll
     for (int r = 0; r < TR; ++r)
 #pragma unroll
-      for (int c = 0; c < TC; ++c) Wk[(r * TC + c) * BT + tid] = a[r][c];
+      for (int c = 0; c < TC; ++c) Wk[(r * TC + c) * NT + tid] = a[r][c];
     if (tid == 0) { io.Wc[qp] = cs; io.rho_io[qp] = rho; io.flag[qp] = 0; }
     return;
   }
@@ -447,7 +454,7 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
   // stage machine replaces the reference's in-loop / post-loop / approximate
   // calls of update_info + check_termination (osqp.c:411-437, 537-581).
   const double alpha = st.alpha, oma = 1.0 - st.alpha, sigma = st.sigma;
-  double *sc = s.red + 8;
+  double *sc = s.red + 13;
   enum { S_PRI, S_DUA, S_OBJ, S_NPRI_S, S_NDUA_S, S_NZ_S, S_NAX_S, S_NQ_S, S_NATY_S, S_NPX_S,
          S_NZ, S_NAX, S_NQ, S_NATY, S_NPX, S_STATUS, S_RHO, S_COUNT_ };
   enum { F_NORMS = 1, F_STATUS = 2, F_APPROX = 4 };
@@ -465,27 +472,27 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
       ++iter;
       if (st.profile) pt0 = wall_clock64();
       // rhs of the reduced system: b = sigma x - q + A'(rho z - y)
-      for (int i = tid; i < m; i += BT) s_w[i] = s_rho[i] * s_z[i] - s_y[i];
+      for (int i = tid; i < m; i += NT) s_w[i] = s_rho[i] * s_z[i] - s_y[i];
       __syncthreads();
-      for (int j = tid; j < NP; j += BT)
+      for (int j = tid; j < NP; j += NT)
         s_b[j] = j < n ? (sigma * s_x[j] - s_q[j]) + a_col_dot(s, s_w, j) : 0.0;
       __syncthreads();
       PSTAMP(0);
-      tile_gemv<TR, TC>(a, s_b, s_xt, s.gp);
+      tile_gemv<TR, TC, GC>(a, s_b, s_xt, s.gp);
       PSTAMP(1);
       for (int r = 0; r < st.refine; ++r) {   // xt += Kinv (b - K xt)
-        for (int i = tid; i < m; i += BT) s_w[i] = s_rho[i] * a_row_dot(s, s_xt, i);
+        for (int i = tid; i < m; i += NT) s_w[i] = s_rho[i] * a_row_dot(s, s_xt, i);
         __syncthreads();
-        for (int j = tid; j < NP; j += BT)
+        for (int j = tid; j < NP; j += NT)
           s_tn[j] = j < n ? s_b[j] - (p_row_dot(s, s_xt, j) + sigma * s_xt[j] + a_col_dot(s, s_w, j)) : 0.0;
         __syncthreads();
-        tile_gemv<TR, TC>(a, s_tn, s_dx, s.gp);        // dx is free until the x update below
-        for (int j = tid; j < n; j += BT) s_xt[j] += s_dx[j];
+        tile_gemv<TR, TC, GC>(a, s_tn, s_dx, s.gp);        // dx is free until the x update below
+        for (int j = tid; j < n; j += NT) s_xt[j] += s_dx[j];
         __syncthreads();
       }
       PSTAMP(2);
       // z~ = A x~ ; x, z, y updates (auxil.c:185-225, proj.c:4-14)
-      for (int i = tid; i < m; i += BT) {
+      for (int i = tid; i < m; i += NT) {
         const double zt = a_row_dot(s, s_xt, i);
         const double zo = s_z[i], yo = s_y[i];
         double v = alpha * zt + oma * zo + s_rinv[i] * yo;
@@ -494,7 +501,7 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
         const double dy = s_rho[i] * (alpha * zt + oma * zo - zn);
         s_z[i] = zn; s_dy[i] = dy; s_y[i] = yo + dy;
       }
-      for (int j = tid; j < n; j += BT) {
+      for (int j = tid; j < n; j += NT) {
         const double xo = s_x[j];
         const double xn = alpha * s_xt[j] + oma * xo;
         s_dx[j] = xn - xo; s_x[j] = xn;
@@ -513,7 +520,7 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
     if (flags & F_NORMS) {
       // ---- update_info: residuals and norms (auxil.c:227-318) ----
       double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
-      for (int i = tid; i < m; i += BT) {
+      for (int i = tid; i < m; i += NT) {
         const double ax = a_row_dot(s, s_x, i);
         const double pr = ax + (-1.0) * s_z[i];
         const double ei = unscaled ? 1.0 / s_E[i] : 1.0;
@@ -521,15 +528,15 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
         m2 = fmax(m2, fabs(ei * s_z[i])); m3 = fmax(m3, fabs(s_z[i]));
         m4 = fmax(m4, fabs(ei * ax)); m5 = fmax(m5, fabs(ax));
       }
-      m0 = b_max(m0, s.red); m1 = b_max(m1, s.red); m2 = b_max(m2, s.red);
-      m3 = b_max(m3, s.red); m4 = b_max(m4, s.red); m5 = b_max(m5, s.red);
+      m0 = b_max<NW>(m0, s.red); m1 = b_max<NW>(m1, s.red); m2 = b_max<NW>(m2, s.red);
+      m3 = b_max<NW>(m3, s.red); m4 = b_max<NW>(m4, s.red); m5 = b_max<NW>(m5, s.red);
       if (tid == 0) {
         sc[S_PRI] = m == 0 ? 0.0 : (unscaled ? m0 : m1);
         sc[S_NPRI_S] = m1; sc[S_NZ] = unscaled ? m2 : m3; sc[S_NZ_S] = m3;
         sc[S_NAX] = unscaled ? m4 : m5; sc[S_NAX_S] = m5;
       }
       double d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, d6 = 0, d7 = 0, ob = 0;
-      for (int j = tid; j < n; j += BT) {
+      for (int j = tid; j < n; j += NT) {
         const double px = p_row_dot(s, s_x, j);
         const double aty = a_col_dot(s, s_y, j);
         double dr = s_q[j] + px;
@@ -541,9 +548,9 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
         d6 = fmax(d6, fabs(di * px)); d7 = fmax(d7, fabs(px));
         ob += s_x[j] * (0.5 * px + s_q[j]);
       }
-      d0 = b_max(d0, s.red); d1 = b_max(d1, s.red); d2 = b_max(d2, s.red); d3 = b_max(d3, s.red);
-      d4 = b_max(d4, s.red); d5 = b_max(d5, s.red); d6 = b_max(d6, s.red); d7 = b_max(d7, s.red);
-      ob = b_sum(ob, s.red);
+      d0 = b_max<NW>(d0, s.red); d1 = b_max<NW>(d1, s.red); d2 = b_max<NW>(d2, s.red); d3 = b_max<NW>(d3, s.red);
+      d4 = b_max<NW>(d4, s.red); d5 = b_max<NW>(d5, s.red); d6 = b_max<NW>(d6, s.red); d7 = b_max<NW>(d7, s.red);
+      ob = b_sum<NW>(ob, s.red);
       if (tid == 0) {
         const double f = unscaled ? cinv : 1.0;
         sc[S_DUA] = unscaled ? d0 * cinv : d1; sc[S_NDUA_S] = d1;
@@ -571,7 +578,7 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
         else {
           // is_primal_infeasible (auxil.c:361-424); projected dy kept in w
           double nd = 0, lhs = 0;
-          for (int i = tid; i < m; i += BT) {
+          for (int i = tid; i < m; i += NT) {
             double dy = s_dy[i];
             if (s_u[i] > BINF) { if (s_l[i] < -BINF) dy = 0.0; else dy = fmin(dy, 0.0); }
             else if (s_l[i] < -BINF) dy = fmax(dy, 0.0);
@@ -579,15 +586,15 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
             nd = fmax(nd, fabs(unscaled ? s_E[i] * dy : dy));
             lhs += s_u[i] * fmax(dy, 0.0) + s_l[i] * fmin(dy, 0.0);
           }
-          nd = b_max(nd, s.red); lhs = b_sum(lhs, s.red);
+          nd = b_max<NW>(nd, s.red); lhs = b_sum<NW>(lhs, s.red);
           if (nd > 1e-30 && lhs < epi * nd) {
             double mx = 0;
-            for (int j = tid; j < n; j += BT) {
+            for (int j = tid; j < n; j += NT) {
               double v = a_col_dot(s, s_w, j);
               if (unscaled) v = v / s_D[j];
               mx = fmax(mx, fabs(v));
             }
-            mx = b_max(mx, s.red);
+            mx = b_max<NW>(mx, s.red);
             pinf = mx < epi * nd;
           }
         }
@@ -595,28 +602,28 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
         else {
           // is_dual_infeasible (auxil.c:426-512)
           double ndx = 0, qdx = 0;
-          for (int j = tid; j < n; j += BT) {
+          for (int j = tid; j < n; j += NT) {
             ndx = fmax(ndx, fabs(unscaled ? s_D[j] * s_dx[j] : s_dx[j]));
             qdx += s_q[j] * s_dx[j];
           }
-          ndx = b_max(ndx, s.red); qdx = b_sum(qdx, s.red);
+          ndx = b_max<NW>(ndx, s.red); qdx = b_sum<NW>(qdx, s.red);
           const double csc_ = unscaled ? cs : 1.0;
           if (ndx > 1e-30 && qdx < csc_ * edi * ndx) {
             double mx = 0;
-            for (int j = tid; j < n; j += BT) {
+            for (int j = tid; j < n; j += NT) {
               double v = p_row_dot(s, s_dx, j);
               if (unscaled) v = v / s_D[j];
               mx = fmax(mx, fabs(v));
             }
-            mx = b_max(mx, s.red);
+            mx = b_max<NW>(mx, s.red);
             if (mx < csc_ * edi * ndx) {
               double viol = 0;
-              for (int i = tid; i < m; i += BT) {
+              for (int i = tid; i < m; i += NT) {
                 double v = a_row_dot(s, s_dx, i);
                 if (unscaled) v = v / s_E[i];
                 if ((s_u[i] < BINF && v > edi * ndx) || (s_l[i] > -BINF && v < -edi * ndx)) viol += 1.0;
               }
-              viol = b_sum(viol, s.red);
+              viol = b_sum<NW>(viol, s.red);
               dinf = viol == 0.0;
             }
           }
@@ -641,14 +648,14 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
         const double rn = fmin(fmax(rho * sqrt(pr / du), 1e-6), 1e6);
         if (rn > rho * st.adapt_tol || rn < rho / st.adapt_tol) {
           rho = rn; rho_updates++;
-          for (int i = tid; i < m; i += BT) {
+          for (int i = tid; i < m; i += NT) {
             const int t = s.ctype[i];
             if (t == 0) { s_rho[i] = rho; s_rinv[i] = 1.0 / rho; }
             else if (t == 1) { s_rho[i] = 1e3 * rho; s_rinv[i] = 1.0 / s_rho[i]; }
           }
           __syncthreads();
-          form_K<TR, TC>(a, n, s, sigma);
-          invert_tiles<TR, TC>(a, s, n);
+          form_K<TR, TC, GC>(a, n, s, sigma);
+          invert_tiles<TR, TC, GC>(a, s, n);
           kinv_dirty = true;
         }
       }
@@ -676,28 +683,28 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
                          status == OSQP_NON_CVX);
   __syncthreads();
   if (has_sol) {
-    for (int j = tid; j < n; j += BT) {
+    for (int j = tid; j < n; j += NT) {
       io.Xo[qp * n + j] = st.scaling ? s_x[j] * s_D[j] : s_x[j];
       io.Xs[qp * n + j] = s_x[j];
     }
-    for (int i = tid; i < m; i += BT) {
+    for (int i = tid; i < m; i += NT) {
       io.Yo[qp * m + i] = st.scaling ? (s_y[i] * s_E[i]) * cinv : s_y[i];
       io.Ys[qp * m + i] = s_y[i]; io.Zs[qp * m + i] = s_z[i];
     }
   } else {
-    for (int j = tid; j < n; j += BT) { io.Xo[qp * n + j] = OSQP_NAN; io.Xs[qp * n + j] = 0.0; }
-    for (int i = tid; i < m; i += BT) { io.Yo[qp * m + i] = OSQP_NAN; io.Ys[qp * m + i] = 0.0; io.Zs[qp * m + i] = 0.0; }
+    for (int j = tid; j < n; j += NT) { io.Xo[qp * n + j] = OSQP_NAN; io.Xs[qp * n + j] = 0.0; }
+    for (int i = tid; i < m; i += NT) { io.Yo[qp * m + i] = OSQP_NAN; io.Ys[qp * m + i] = 0.0; io.Zs[qp * m + i] = 0.0; }
     if (status == OSQP_PRIMAL_INFEASIBLE || status == OSQP_PRIMAL_INFEASIBLE_INACCURATE) {
       double mx = 0;
-      for (int i = tid; i < m; i += BT) { s_w[i] = unscaled ? s_w[i] * s_E[i] : s_w[i]; mx = fmax(mx, fabs(s_w[i])); }
-      mx = b_max(mx, s.red);
-      for (int i = tid; i < m; i += BT) io.DYo[qp * m + i] = s_w[i] * (1.0 / mx);
+      for (int i = tid; i < m; i += NT) { s_w[i] = unscaled ? s_w[i] * s_E[i] : s_w[i]; mx = fmax(mx, fabs(s_w[i])); }
+      mx = b_max<NW>(mx, s.red);
+      for (int i = tid; i < m; i += NT) io.DYo[qp * m + i] = s_w[i] * (1.0 / mx);
     }
     if (status == OSQP_DUAL_INFEASIBLE || status == OSQP_DUAL_INFEASIBLE_INACCURATE) {
       double mx = 0;
-      for (int j = tid; j < n; j += BT) { s_tn[j] = unscaled ? s_dx[j] * s_D[j] : s_dx[j]; mx = fmax(mx, fabs(s_tn[j])); }
-      mx = b_max(mx, s.red);
-      for (int j = tid; j < n; j += BT) io.DXo[qp * n + j] = s_tn[j] * (1.0 / mx);
+      for (int j = tid; j < n; j += NT) { s_tn[j] = unscaled ? s_dx[j] * s_D[j] : s_dx[j]; mx = fmax(mx, fabs(s_tn[j])); }
+      mx = b_max<NW>(mx, s.red);
+      for (int j = tid; j < n; j += NT) io.DXo[qp * n + j] = s_tn[j] * (1.0 / mx);
     }
   }
   if (st.profile && tid == 0) {
@@ -710,7 +717,7 @@ __global__ void __launch_bounds__(BT) k_batch_solve(BPattern p, BSettings st, BI
 #pragma unroll
     for (int r = 0; r < TR; ++r)
 #pragma unroll
-      for (int c = 0; c < TC; ++c) Wk[(r * TC + c) * BT + tid] = a[r][c];
+      for (int c = 0; c < TC; ++c) Wk[(r * TC + c) * NT + tid] = a[r][c];
   }
   if (tid == 0) {
     io.flag[qp] = 0;
@@ -755,7 +762,7 @@ __global__ void __launch_bounds__(256) k_batch_update(int n, int m, BIO io, cons
 // host side
 // ---------------------------------------------------------------------------
 struct osqp_amd_batch {
-  int device = 0, tile = 8;
+  int device = 0, tile = 8, threads = 512;
   long long B = 0;
   int n = 0, m = 0, nnzP = 0, nnzA = 0;
   hipStream_t stream = nullptr;
@@ -768,6 +775,9 @@ struct osqp_amd_batch {
   std::vector<double> h_info;
   double *dQ = nullptr, *dL = nullptr, *dU = nullptr;   // staging for updates
 };
+
+static void batch_launch(osqp_amd_batch *b, int phase);
+static void batch_set_lds(osqp_amd_batch *b);
 
 template <typename Tp>
 static int balloc(osqp_amd_batch *b, Tp **p, size_t cnt) {
@@ -834,6 +844,10 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
   b->device = (int)device; b->B = batch; b->n = n; b->m = m;
   b->nnzP = (int)P->p[n]; b->nnzA = (int)A->p[n];
   b->tile = n <= 64 ? 4 : 8;
+  {
+    const char *t = getenv("OSQP_AMD_BATCH_THREADS");
+    b->threads = (t && atoi(t) == 256) ? 256 : 512;   // 512 (8x4 tiles) measured faster than 256 (8x8 tiles spill)
+  }
   if (hipSetDevice(b->device) != hipSuccess || hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
     delete b; return OSQP_LINSYS_SOLVER_LOAD_ERROR;
   }
@@ -912,7 +926,7 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
   if (rc || hipStreamSynchronize(b->stream) != hipSuccess) { osqp_amd_batch_cleanup(b); return OSQP_LINSYS_SOLVER_INIT_ERROR; }
 
   const int NP = 16 * b->tile;
-  b->lds_bytes = sizeof(double) * ((size_t)b->nnzP + b->nnzA + 7 * NP + 11 * (size_t)m + 4 * NP + 32 + 33 * NP) +
+  b->lds_bytes = sizeof(double) * ((size_t)b->nnzP + b->nnzA + 7 * NP + 11 * (size_t)m + 4 * NP + 64 + (size_t)(b->threads / 16 + 1) * NP) +
                  sizeof(int) * ((size_t)m + 4 + 3 * ((size_t)n + 1) + 2 * (size_t)b->nnzP + 2 * (size_t)Fp[n] +
                                 4 * (size_t)b->nnzA + (size_t)m + 1);
   b->lds_bytes = (b->lds_bytes + 15) & ~(size_t)15;
@@ -921,24 +935,30 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
     osqp_amd_batch_cleanup(b);
     return OSQP_LINSYS_SOLVER_INIT_ERROR;
   }
-  if (b->lds_bytes > 64 * 1024) {
-    if (b->tile == 8) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_solve<8, 4>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes);
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_solve<4, 2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes);
-  }
+  if (b->lds_bytes > 64 * 1024) batch_set_lds(b);
   b->h_info.assign(B * 8, 0.0);
   // setup phase on the device: Ruiz scaling, rho classes, K^-1 (one workgroup per QP)
-  if (b->tile == 8)
-    hipLaunchKernelGGL((k_batch_solve<8, 4>), dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, 0);
-  else
-    hipLaunchKernelGGL((k_batch_solve<4, 2>), dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, 0);
+  batch_launch(b, 0);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) {
     osqp_amd_batch_cleanup(b);
     return OSQP_LINSYS_SOLVER_INIT_ERROR;
   }
   *out = b;
   return 0;
+}
+
+static void batch_launch(osqp_amd_batch *b, int phase) {
+  const dim3 g((unsigned)b->B);
+#define BL_(TR, TC, GC) hipLaunchKernelGGL((k_batch_solve<TR, TC, GC>), g, dim3(16 * GC), b->lds_bytes, b->stream, b->pat, b->st, b->io, phase)
+  if (b->tile == 8) { if (b->threads == 512) BL_(8, 4, 32); else BL_(8, 8, 16); }
+  else              { if (b->threads == 512) BL_(4, 2, 32); else BL_(4, 4, 16); }
+#undef BL_
+}
+static void batch_set_lds(osqp_amd_batch *b) {
+#define SA_(TR, TC, GC) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_solve<TR, TC, GC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes)
+  if (b->tile == 8) { if (b->threads == 512) SA_(8, 4, 32); else SA_(8, 8, 16); }
+  else              { if (b->threads == 512) SA_(4, 2, 32); else SA_(4, 4, 16); }
+#undef SA_
 }
 
 extern "C" void osqp_amd_batch_cleanup(osqp_amd_batch *b) {
@@ -969,10 +989,7 @@ extern "C" c_int osqp_amd_batch_update(osqp_amd_batch *b, const c_float *Q, cons
 extern "C" c_int osqp_amd_batch_solve(osqp_amd_batch *b) {
   if (!b) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   BCHK(hipSetDevice(b->device));
-  if (b->tile == 8)
-    hipLaunchKernelGGL((k_batch_solve<8, 4>), dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, 1);
-  else
-    hipLaunchKernelGGL((k_batch_solve<4, 2>), dim3((unsigned)b->B), dim3(BT), b->lds_bytes, b->stream, b->pat, b->st, b->io, 1);
+  batch_launch(b, 1);
   BCHK(hipGetLastError());
   BCHK(hipStreamSynchronize(b->stream));
   b->solves++;
