@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-n", type=int, default=2000, help="size of the bounded CPU sample (m = 2n)")
     ap.add_argument("--batch", type=int, default=1024, help="MPC batch size for the QPs/s leg (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     return ap.parse_args()
 
 
@@ -108,7 +109,7 @@ def cpu_baseline(n, eps):
                 setup_s=round(t_setup, 3), host_cpus=os.cpu_count())
 
 
-def bench_batch(batch, dist, rank, local_rank, world, steps=10, with_cpu=True):
+def bench_batch(batch, dist, rank, local_rank, world, coll_dev, steps=10, with_cpu=True):
     """Config 4: `batch` MPC QPs (n=120, m=240), contiguous shards of batch/world per
     rank, no communication during the solves, one all_gather of the records."""
     import torch
@@ -134,13 +135,13 @@ def bench_batch(batch, dist, rank, local_rank, world, steps=10, with_cpu=True):
     rec = np.concatenate([r.x, r.y, r.info_raw], axis=1)
     if dist is not None:      # the one collective of the batch path: gather of the per-QP records
         pad = np.zeros((per, rec.shape[1])); pad[:rec.shape[0]] = rec
-        t = torch.from_numpy(pad).cuda()
+        t = torch.from_numpy(pad).to(coll_dev)
         out = torch.empty((world * per, rec.shape[1]), dtype=t.dtype, device=t.device)
         tg = time.perf_counter()
         dist.all_gather_into_tensor(out, t)
         torch.cuda.synchronize()
         gather_ms = 1e3 * (time.perf_counter() - tg)
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         rec = out.cpu().numpy()[:batch]
@@ -178,16 +179,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    ndev = max(1, torch.cuda.device_count())
+    dev_id = local_rank % ndev          # == local_rank on a real multi-GPU node
+    torch.cuda.set_device(dev_id)
+    coll_dev = torch.device("cuda", dev_id) if a.backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=coll_dev)
+        else:
+            dist.init_process_group(a.backend)
     import osqp_amd
     from osqp_amd.problems import random_sparse_qp
-    osqp_amd.set_engine_options(device=local_rank)
+    osqp_amd.set_engine_options(device=dev_id)
 
     pb = random_sparse_qp(a.n, a.m, seed=1 + rank)
     settings = dict(eps_abs=a.eps, eps_rel=a.eps, adaptive_rho_interval=100, warm_start=0, verbose=0)
@@ -212,15 +217,15 @@ def main():
 
     tot_iters, max_t = float(iters), elapsed
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        it = torch.tensor([float(iters)], dtype=torch.float64, device="cuda")
+        it = torch.tensor([float(iters)], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(it, op=dist.ReduceOp.SUM)
         max_t, tot_iters = float(t.item()), float(it.item())
 
     batch = None
     if a.batch:
-        batch = bench_batch(a.batch, dist, rank, local_rank, world, with_cpu=not a.no_cpu)
+        batch = bench_batch(a.batch, dist, rank, dev_id, world, coll_dev, with_cpu=not a.no_cpu)
 
     if rank == 0:
         st = solver.stats()
