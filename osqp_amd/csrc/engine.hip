@@ -66,6 +66,7 @@ struct __attribute__((aligned(32))) G4 { double r, w, s, m; };
 
 struct DevMat {
   int nrows, nblk;
+  int nstream;           // blocks [0,nstream) are multi-row stream blocks, [nstream,nblk) single long rows
   const int    *rowptr;
   const int    *col;
   const double *val;
@@ -261,6 +262,22 @@ __device__ __forceinline__ double long_row_dot(const DevMat &Mx, int ka, int kb,
   }
   for (; k < kb; k += TB) s0 += Mx.val[k] * in[Mx.col[k]];
   return block_sum((s0 + s1) + (s2 + s3), red);
+}
+
+// One wavefront per long row: lanes stride the row, four independent
+// index/value/gather chains per lane, 64-lane reduction; no LDS, no barrier.
+template <class F>
+__device__ __forceinline__ double wave_row_dot(const DevMat &Mx, int ka, int kb, F xval) {
+  const int lane = threadIdx.x & 63;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = ka + lane;
+  for (; k + 192 < kb; k += 256) {
+    const int c0 = Mx.col[k], c1 = Mx.col[k + 64], c2 = Mx.col[k + 128], c3 = Mx.col[k + 192];
+    const double v0 = Mx.val[k], v1 = Mx.val[k + 64], v2 = Mx.val[k + 128], v3 = Mx.val[k + 192];
+    s0 += v0 * xval(c0); s1 += v1 * xval(c1); s2 += v2 * xval(c2); s3 += v3 * xval(c3);
+  }
+  for (; k < kb; k += 64) s0 += Mx.val[k] * xval(Mx.col[k]);
+  return wave_sum((s0 + s1) + (s2 + s3));      // valid in lane 0
 }
 
 #define LDS_DECL(NV)                                   \
@@ -500,11 +517,11 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   const int iters_prev = st->iters[(it + 1) & 1];
   const double tol2_old = st->tol2, gam_old = st->gam[(it + 1) & 1], alp_old = st->alp[(it + 1) & 1];
   const Params prm = *c.prm;
-  const bool has_blk = (int)blockIdx.x < c.A.nblk;
+  const bool has_blk = (int)blockIdx.x < c.A.nstream;
   RowBlk b = {0, 0, 0, 0};
   if (has_blk) b = c.A.blk[blockIdx.x];
   const int cnt = b.k1 - b.k0;
-  const bool small = has_blk && !IS_LONG(b);
+  const bool small = has_blk;
   const G4 *gold = c.g4 + (size_t)((it + 1) & 1) * c.n;
   G4 *gnew = c.g4 + (size_t)(it & 1) * c.n;
   int ecol[EPT]; double eval[EPT], g0[EPT], g1[EPT], g2[EPT], g3[EPT];
@@ -594,81 +611,59 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   if (upd_only) return;
   // ---- t = rho . (A u_new) ----
   double *t = c.ut + c.n;
-  for (int bi = blockIdx.x; bi < c.A.nblk; bi += gridDim.x) {
+  for (int bi = blockIdx.x; bi < c.A.nstream; bi += gridDim.x) {
     if (bi != (int)blockIdx.x) { b = c.A.blk[bi]; RL = lanes_for(b.r1 - b.r0); rg = threadIdx.x / RL; rlane = threadIdx.x % RL; }
     const int cn = b.k1 - b.k0;
-    if (IS_LONG(b) && pre) {         // single long row, plain gather of u
-      const double acc = long_row_dot(c.A, b.k0, b.k1, c.ut, red);
-      if (threadIdx.x == 0) t[b.r0] = c.rho[b.r0] * acc;
-    } else if (IS_LONG(b)) {         // single long row: strided dot by the whole workgroup
-      double acc = 0.0;
-      for (int k = b.k0 + threadIdx.x; k < b.k1; k += TB) {
-        const int cc = c.A.col[k];
+    if (bi != (int)blockIdx.x) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int k = threadIdx.x + e * TB;
+        if (k < cn) { ecol[e] = c.A.col[b.k0 + k]; eval[e] = c.A.val[b.k0 + k]; }
+      }
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int k = threadIdx.x + e * TB;
+        if (k < cn) {
+          const int cc = ecol[e];
+          if (pre) g0[e] = c.ut[cc];
+          else { const G4 g = gold[cc]; g0[e] = g.r; g1[e] = g.w; g2[e] = g.s; g3[e] = g.m; }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int k = threadIdx.x + e * TB;
+      if (k < cn) {
         double uv;
-        if (pre) uv = c.ut[cc];
+        if (pre) uv = g0[e];
         else {
-          const G4 g = gold[cc];
-          const double sj = first ? g.w : (g.w + beta * g.s);
-          uv = g.m * (g.r - alpha * sj);
+          const double sj = first ? g1[e] : (g1[e] + beta * g2[e]);
+          uv = g3[e] * (g0[e] - alpha * sj);
         }
-        acc += c.A.val[k] * uv;
-      }
-      acc = block_sum(acc, red);
-      if (threadIdx.x == 0) t[b.r0] = c.rho[b.r0] * acc;
-    } else {
-      if (bi == (int)blockIdx.x) {   // prefetched entries
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-          const int k = threadIdx.x + e * TB;
-          if (k < cn) {
-            double uv;
-            if (pre) uv = g0[e];
-            else {
-              const double sj = first ? g1[e] : (g1[e] + beta * g2[e]);
-              uv = g3[e] * (g0[e] - alpha * sj);
-            }
-            lprod[k] = eval[e] * uv;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-          const int k = threadIdx.x + e * TB;
-          if (k < cn) { ecol[e] = c.A.col[b.k0 + k]; eval[e] = c.A.val[b.k0 + k]; }
-        }
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-          const int k = threadIdx.x + e * TB;
-          if (k < cn) {
-            const int cc = ecol[e];
-            if (pre) g0[e] = c.ut[cc];
-            else { const G4 g = gold[cc]; g0[e] = g.r; g1[e] = g.w; g2[e] = g.s; g3[e] = g.m; }
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-          const int k = threadIdx.x + e * TB;
-          if (k < cn) {
-            double uv;
-            if (pre) uv = g0[e];
-            else {
-              const double sj = first ? g1[e] : (g1[e] + beta * g2[e]);
-              uv = g3[e] * (g0[e] - alpha * sj);
-            }
-            lprod[k] = eval[e] * uv;
-          }
-        }
-      }
-      __syncthreads();
-      for (int i = b.r0 + rg; i < b.r1; i += TB / RL) {
-        int a0, a1;
-        if (bi == (int)blockIdx.x && i == b.r0 + rg) { a0 = rp0; a1 = rp1; }
-        else { a0 = c.A.rowptr[i]; a1 = c.A.rowptr[i + 1]; }
-        const double acc = row_sum_par(lprod, a0 - b.k0, a1 - b.k0, rlane, RL);
-        if (rlane == 0) t[i] = c.rho[i] * acc;
+        lprod[k] = eval[e] * uv;
       }
     }
     __syncthreads();
+    for (int i = b.r0 + rg; i < b.r1; i += TB / RL) {
+      int a0, a1;
+      if (bi == (int)blockIdx.x && i == b.r0 + rg) { a0 = rp0; a1 = rp1; }
+      else { a0 = c.A.rowptr[i]; a1 = c.A.rowptr[i + 1]; }
+      const double acc = row_sum_par(lprod, a0 - b.k0, a1 - b.k0, rlane, RL);
+      if (rlane == 0) t[i] = c.rho[i] * acc;
+    }
+    __syncthreads();
+  }
+  // long rows: one wavefront each
+  for (int bi = c.A.nstream + blockIdx.x * (TB / 64) + (threadIdx.x >> 6); bi < c.A.nblk; bi += gridDim.x * (TB / 64)) {
+    const RowBlk lb = c.A.blk[bi];
+    double acc;
+    if (pre) acc = wave_row_dot(c.A, lb.k0, lb.k1, [&](int cc) { return c.ut[cc]; });
+    else acc = wave_row_dot(c.A, lb.k0, lb.k1, [&](int cc) {
+      const G4 g = gold[cc];
+      const double sj = first ? g.w : (g.w + beta * g.s);
+      return g.m * (g.r - alpha * sj);
+    });
+    if ((threadIdx.x & 63) == 0) t[lb.r0] = c.rho[lb.r0] * acc;
   }
 }
 
@@ -678,11 +673,11 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   const bool bench = flags & 4;
   const int run = st->run, done = st->done;
   const double sigma = c.prm->sigma;
-  const bool has_blk = (int)blockIdx.x < c.M.nblk;
+  const bool has_blk = (int)blockIdx.x < c.M.nstream;
   RowBlk b = {0, 0, 0, 0};
   if (has_blk) b = c.M.blk[blockIdx.x];
   const int cnt = b.k1 - b.k0;
-  const bool small = has_blk && !IS_LONG(b);
+  const bool small = has_blk;
   double ev[EPT];
   int RL = lanes_for(b.r1 - b.r0);
   int rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
@@ -706,35 +701,36 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   LDS_DECL(1);
   G4 *gc = c.g4 + (size_t)(it & 1) * c.n;
   double pg = 0, pd = 0, prr = 0;
-  for (int bi = blockIdx.x; bi < c.M.nblk; bi += gridDim.x) {
+  for (int bi = blockIdx.x; bi < c.M.nstream; bi += gridDim.x) {
     if (bi != (int)blockIdx.x) { b = c.M.blk[bi]; RL = lanes_for(b.r1 - b.r0); rg = threadIdx.x / RL; rlane = threadIdx.x % RL; }
     const int cn = b.k1 - b.k0;
-    if (IS_LONG(b)) {
-      const double acc = long_row_dot(c.M, b.k0, b.k1, c.ut, red);
-      if (threadIdx.x == 0) {
-        const int j = b.r0;
-        const double uj = c.ut[j], wj = acc + sigma * uj, rj = gc[j].r;
-        gc[j].w = wj; pg += rj * uj; pd += wj * uj; prr += rj * rj;
-      }
-    } else {
-      if (bi == (int)blockIdx.x) {
+    if (bi == (int)blockIdx.x) {
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) { const int k = threadIdx.x + e * TB; if (k < cn) lprod[k] = ev[e]; }
-      } else stage_products<1>(c.M, b, c.ut, nullptr, lprod, nullptr);
-      __syncthreads();
-      for (int j = b.r0 + rg; j < b.r1; j += TB / RL) {
-        int a0, a1;
-        if (bi == (int)blockIdx.x && j == b.r0 + rg) { a0 = rp0; a1 = rp1; }
-        else { a0 = c.M.rowptr[j]; a1 = c.M.rowptr[j + 1]; }
-        const double acc = row_sum_par(lprod, a0 - b.k0, a1 - b.k0, rlane, RL);
-        if (rlane == 0) {
-          const double uj = c.ut[j], wj = acc + sigma * uj, rj = gc[j].r;
-          gc[j].w = wj;
-          pg += rj * uj; pd += wj * uj; prr += rj * rj;
-        }
+      for (int e = 0; e < EPT; ++e) { const int k = threadIdx.x + e * TB; if (k < cn) lprod[k] = ev[e]; }
+    } else stage_products<1>(c.M, b, c.ut, nullptr, lprod, nullptr);
+    __syncthreads();
+    for (int j = b.r0 + rg; j < b.r1; j += TB / RL) {
+      int a0, a1;
+      if (bi == (int)blockIdx.x && j == b.r0 + rg) { a0 = rp0; a1 = rp1; }
+      else { a0 = c.M.rowptr[j]; a1 = c.M.rowptr[j + 1]; }
+      const double acc = row_sum_par(lprod, a0 - b.k0, a1 - b.k0, rlane, RL);
+      if (rlane == 0) {
+        const double uj = c.ut[j], wj = acc + sigma * uj, rj = gc[j].r;
+        gc[j].w = wj;
+        pg += rj * uj; pd += wj * uj; prr += rj * rj;
       }
     }
     __syncthreads();
+  }
+  // long rows: one wavefront each
+  for (int bi = c.M.nstream + blockIdx.x * (TB / 64) + (threadIdx.x >> 6); bi < c.M.nblk; bi += gridDim.x * (TB / 64)) {
+    const RowBlk lb = c.M.blk[bi];
+    const double acc = wave_row_dot(c.M, lb.k0, lb.k1, [&](int cc) { return c.ut[cc]; });
+    if ((threadIdx.x & 63) == 0) {
+      const int j = lb.r0;
+      const double uj = c.ut[j], wj = acc + sigma * uj, rj = gc[j].r;
+      gc[j].w = wj; pg += rj * uj; pd += wj * uj; prr += rj * rj;
+    }
   }
   if (flags & 32) { if (pg == 12345.678) c.kp[0] = pd + prr; return; }                // timing probe: no block reductions
   block_sum3(pg, pd, prr, red);
@@ -1015,7 +1011,7 @@ __global__ void __launch_bounds__(TB) k_certificates(Ctx c, double eps_dx, int u
 // host side
 // ---------------------------------------------------------------------------
 struct HostMat {         // host image of a device CSR matrix
-  int nrows = 0, ncols = 0;
+  int nrows = 0, ncols = 0, nstream = 0;
   std::vector<int> rowptr, col, split;
   std::vector<double> val;
   std::vector<RowBlk> blk;
@@ -1062,21 +1058,22 @@ static int dev_alloc(hipeng *e, T **p, size_t count) {
 // Greedy row blocks: as many whole rows as fit `chunk` products (at least one
 // row; a single row may exceed MAX_CHUNK and then takes the long-row path).
 static void build_blocks(HostMat &H, int chunk) {
+  // stream blocks first (runs of consecutive short rows, at most `chunk` products),
+  // then one block per long row: the PCG kernels give each long row a wavefront
   H.blk.clear();
+  std::vector<RowBlk> longs;
   int r = 0;
   while (r < H.nrows) {
     const int k0 = H.rowptr[r];
-    if (H.rowptr[r + 1] - k0 >= LONG_ROW) {          // long row: a block of its own
-      H.blk.push_back({r, r + 1, k0, H.rowptr[r + 1]});
-      r++;
-      continue;
-    }
+    if (H.rowptr[r + 1] - k0 >= LONG_ROW) { longs.push_back({r, r + 1, k0, H.rowptr[r + 1]}); r++; continue; }
     int r1 = r + 1;
     while (r1 < H.nrows && H.rowptr[r1 + 1] - H.rowptr[r1] < LONG_ROW &&
            H.rowptr[r1 + 1] - k0 <= chunk && (r1 - r) < 8 * TB) r1++;
     H.blk.push_back({r, r1, k0, H.rowptr[r1]});
     r = r1;
   }
+  H.nstream = (int)H.blk.size();
+  H.blk.insert(H.blk.end(), longs.begin(), longs.end());
 }
 
 static int pick_chunk(long long nnz, int nrows) {
@@ -1110,7 +1107,7 @@ static int upload_mat(hipeng *e, HostMat &H) {
 
 static DevMat dev_view(const HostMat &H) {
   DevMat d;
-  d.nrows = H.nrows; d.nblk = (int)H.blk.size();
+  d.nrows = H.nrows; d.nblk = (int)H.blk.size(); d.nstream = H.nstream;
   d.rowptr = H.d_rowptr; d.col = H.d_col; d.val = H.d_val; d.split = H.d_split; d.blk = H.d_blk;
   return d;
 }
@@ -1229,7 +1226,13 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
     return rl;
   };
   e->rlA = pick_rl(e->A); e->rlM = pick_rl(e->M);
-  e->split = false;   // experimental (OSQP_AMD_SPLIT=1): not faster on config 3 in round 1
+  {
+    // when most of A sits in long rows, a 32-byte record gather per entry dominates k_cg_A:
+    // do the vector update in its own (tiny) launch and gather plain 8-byte u instead
+    long long lnnz = 0;
+    for (size_t q = (size_t)e->A.nstream; q < e->A.blk.size(); q++) lnnz += e->A.blk[q].k1 - e->A.blk[q].k0;
+    e->split = 2 * lnnz >= (long long)e->A.val.size() && !e->A.val.empty();
+  }
   if (const char *sp = getenv("OSQP_AMD_SPLIT")) e->split = atoi(sp) != 0;
   if (upload_mat(e, e->A) || upload_mat(e, e->M)) return HIPENG_ERR_HIP;
   Ctx &c = e->c;
