@@ -63,6 +63,7 @@ typedef struct {
   c_int pcg_forced;      /* solves accepted at pcg_max_iter without converging */
   c_int graph_launches;
   c_int kernels_per_pcg_iter;
+  c_int neg_curvature;   /* solves in which CG met p'Kp <= 0 (K not positive definite) */
 } hipeng_stats;
 
 /* Create the device-resident problem.  P (upper triangle) and A are the

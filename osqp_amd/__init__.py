@@ -10,8 +10,9 @@ from . import _abi as abi
 from ._lib import lib, build, LIB_PATH
 from .interface import SolverHandle, Results
 from .batch import BatchOSQP
+from .multi import solve_many
 
-__all__ = ["OSQP", "BatchOSQP", "abi", "lib", "build", "engine_options", "set_engine_options"]
+__all__ = ["OSQP", "BatchOSQP", "solve_many", "abi", "lib", "build", "engine_options", "set_engine_options"]
 
 
 class _Options(C.Structure):

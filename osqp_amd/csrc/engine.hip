@@ -1547,6 +1547,7 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   e->stats.pcg_iters_last = s.iters_last;
   e->stats.pcg_iters_max = s.iters_max;
   e->stats.pcg_forced = s.forced;
+  e->stats.neg_curvature = s.neg_curv_seen;
   return 0;
 }
 

@@ -544,6 +544,31 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
     return setup_fail(OSQP_LINSYS_SOLVER_LOAD_ERROR, "no HIP device: the HIP PCG solver cannot be loaded");
   if (rc) return setup_fail(OSQP_LINSYS_SOLVER_INIT_ERROR, "HIP engine initialisation failed");
   if (w->scaling) hipeng_set_scaling(s->eng, w->scaling->D, w->scaling->E, w->scaling->c);
+  /* Convexity probe.  The reference rejects a KKT matrix whose LDL^T factor has fewer than n
+   * positive pivots (qdldl_interface.c:93-99, OSQP_NONCVX_ERROR), i.e. a reduced matrix
+   * P + sigma I + A' rho A that is not positive definite.  An iterative solver has no inertia;
+   * the equivalent signal is negative curvature p'Kp <= 0 met by CG.  A short CG run on a
+   * fixed pseudo-random right-hand side is a best-effort version of that test. */
+  {
+    c_int probe = HMIN(HMAX(2 * n, 8), 64);
+    hipeng_params pp = prm;
+    pp.pcg_max_iter = probe;
+    c_float *rhs = (c_float *)malloc((size_t)(n + m + 1) * sizeof(c_float));
+    unsigned long long lcg = 88172645463325252ULL;
+    if (!rhs) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
+    for (c_int k = 0; k < n + m; k++) {
+      lcg = lcg * 6364136223846793005ULL + 1442695040888963407ULL;
+      rhs[k] = (c_float)((lcg >> 11) & 0xFFFFF) / 1048576.0 - 0.5;
+    }
+    hipeng_stats hs;
+    int bad = hipeng_set_params(s->eng, &pp) || hipeng_kkt_solve(s->eng, rhs) || hipeng_get_stats(s->eng, &hs);
+    free(rhs);
+    if (bad) return setup_fail(OSQP_LINSYS_SOLVER_INIT_ERROR, "HIP engine initialisation failed");
+    if (hs.neg_curvature > 0)
+      return setup_fail(OSQP_NONCVX_ERROR, "KKT matrix factorization.\nThe problem seems to be non-convex");
+    hipeng_set_params(s->eng, &prm);
+    hipeng_cold_start(s->eng);
+  }
 
   w->info->status_polish = 0;
   put_status(w->info, OSQP_UNSOLVED);

@@ -361,3 +361,18 @@ def test_full_size_config2_matches_oracle_golden(gpu_lib):
     assert np.abs(r.y[::20] - ys).max() <= 1e-6 * g["y_inf"]
     assert abs(r.info.pri_res - gi["pri"]) <= 1e-4 * gi["pri"] + 1e-9
     assert abs(r.info.dua_res - gi["dua"]) <= 1e-4 * gi["dua"] + 1e-9
+
+
+def test_non_cvx_golden(gpu_lib):
+    """tests/non_cvx/test_non_cvx.h:26-58: indefinite P.  With sigma = 1e-6 the reduced
+    matrix is not positive definite and setup must fail with OSQP_NONCVX_ERROR (5) -- the
+    reference gets it from the LDL^T inertia, this engine from negative curvature met by a
+    short CG probe; with sigma = 5 setup succeeds and the solve must end OSQP_NON_CVX with
+    obj_val == OSQP_NAN."""
+    import osqp_amd
+    from osqp_amd import abi
+    pb, sol = load_golden("non_cvx")
+    with pytest.raises(ValueError, match="error 5"):
+        osqp_amd.OSQP().setup(**pb, adaptive_rho=0, sigma=1e-6)
+    r = osqp_amd.OSQP().setup(**pb, adaptive_rho=0, sigma=float(sol["sigma_new"])).solve()
+    assert r.info.status_val == abi.OSQP_NON_CVX and r.info.obj_val == abi.OSQP_NAN
