@@ -241,6 +241,7 @@ def main():
                        "admm_iters_per_solve": int(last.info.iter), "status": last.info.status,
                        "rho_updates": int(last.info.rho_updates),
                        "pcg_iters_per_admm_iter": round(st["pcg_iters_total"] / max(1, (a.steps + a.warmup) * last.info.iter), 2),
+                       "graph_launches": st["graph_launches"], "host_syncs": st["host_syncs"],
                        "parallelism": "replicas x%d (a single QP does not shard)" % world},
         }
         if world == 1:

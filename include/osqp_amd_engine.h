@@ -80,6 +80,12 @@ int hipeng_set_params(hipeng *e, const hipeng_params *prm);
 /* D, E, Dinv, Einv vectors (NULL = identity) and cost scaling c: needed only
  * for the unscaled norms of hipeng_residuals (src/scaling.c:177-192). */
 int hipeng_set_scaling(hipeng *e, const c_float *D, const c_float *E, c_float c);
+/* scale_data (src/scaling.c:44-156) on the device: Ruiz-equilibrates the resident raw problem
+ * in place (`passes` = settings->scaling) and returns D, E, c and the scaled q, l, u, triu(P) and A
+ * values (CSC order of the matrices given to hipeng_create) for the host mirrors. */
+int hipeng_ruiz_scale(hipeng *e, c_int passes, c_float *D, c_float *E, c_float *cost,
+                      c_float *q, c_float *l, c_float *u, c_float *Px, c_float *Ax);
+int hipeng_matrices_changed(hipeng *e);   /* after an in-place rescale: preconditioner, z~, rhs parts */
 int hipeng_upload_q(hipeng *e, const c_float *q);                      /* osqp_update_lin_cost, osqp.c:765 */
 int hipeng_upload_bounds(hipeng *e, const c_float *l, const c_float *u); /* osqp_update_bounds, osqp.c:797 */
 /* update_rho_vec of the vtable (qdldl_interface.c:396-410): re-uploads rho and
@@ -111,6 +117,7 @@ int hipeng_certificates(hipeng *e, c_float eps_dx, int unscaled, hipeng_scalars 
 int hipeng_download(hipeng *e, c_float *x, c_float *y, c_float *z, c_float *dx,
                     c_float *dy, int dy_projected);
 int hipeng_get_stats(hipeng *e, hipeng_stats *st);
+int hipeng_reset_stats(hipeng *e);   /* zero the counters (after the setup-time convexity probe) */
 int hipeng_sync(hipeng *e);
 
 /* Plugin-boundary solve (LinSysSolver.solve, include/types.h:300-301;

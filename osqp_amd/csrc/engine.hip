@@ -94,7 +94,7 @@ struct State {
 
 struct Params {          // mutable scalars (host writes, kernels read)
   double sigma, alpha, eps_rel, eps_abs, cinv;
-  int    pcg_max_iter, use_cvec, has_scaling, pad;
+  int    pcg_max_iter, use_cvec, has_scaling, k_expect;   // k_expect: PCG iterations the host expects per solve
 };
 
 struct Ctx {             // static pointers / sizes, passed by value
@@ -512,6 +512,9 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   State *st = c.st;
   const bool cont = flags & 2, bench = flags & 4, upd_only = flags & 16, apply_only = flags & 32;
   const bool pre = (flags & 8) || apply_only;   // gather u directly (no recompute)
+  // unrolled iterations beyond the expected count are almost always no-ops: look at the
+  // flags first there instead of prefetching speculatively
+  if (!bench && !cont && it > c.prm->k_expect && (!st->run || st->done)) return;
   // ---- issue every independent load before looking at the flags ----
   const int stalled = st->stalled, run = st->run, done = st->done, neg = st->neg_curv;
   const int iters_prev = st->iters[(it + 1) & 1];
@@ -671,6 +674,7 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   if (flags & 64) return;                                                            // timing probe: empty kernel
   State *st = c.st;
   const bool bench = flags & 4;
+  if (!bench && it > c.prm->k_expect && (!st->run || st->done)) return;
   const int run = st->run, done = st->done;
   const double sigma = c.prm->sigma;
   const bool has_blk = (int)blockIdx.x < c.M.nstream;
@@ -1008,6 +1012,122 @@ __global__ void __launch_bounds__(TB) k_certificates(Ctx c, double eps_dx, int u
 }
 
 // ---------------------------------------------------------------------------
+// Ruiz equilibration on the device (reference src/scaling.c:44-156).  One wavefront
+// per matrix row; the products are formed in the reference's order
+// ((val * row factor) * column factor, then * c) so both device copies of A hold the
+// same bits.  Scratch: dn (n), en (m) live in kp / dy; scalars in scal[SC_RUIZ..].
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double clip_scaling(double v) {
+  if (v < 1e-4) v = 1.0;
+  if (v > 1e4) v = 1e4;
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+// dn[j] = 1/sqrt(clip(max |column j of [P;A]|)), en[i] = 1/sqrt(clip(max |row i of A|))
+__global__ void __launch_bounds__(TB) k_ruiz_norms(Ctx c, double *dn, double *en) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6), nw = gridDim.x * (TB / 64);
+  for (int r = w; r < c.n + c.m; r += nw) {
+    const bool isM = r < c.n;
+    const DevMat &X = isM ? c.M : c.A;
+    const int row = isM ? r : r - c.n;
+    double mx = 0.0;
+    for (int k = X.rowptr[row] + lane; k < X.rowptr[row + 1]; k += 64) mx = fmax(mx, fabs(X.val[k]));
+    mx = wave_max(mx);
+    if (lane == 0) { if (isM) dn[row] = 1.0 / sqrt(clip_scaling(mx)); else en[row] = 1.0 / sqrt(clip_scaling(mx)); }
+  }
+}
+
+// apply the pass: matrices, q, accumulated D and E
+__global__ void __launch_bounds__(TB) k_ruiz_apply(Ctx c, const double *dn, const double *en,
+                                                   double *Mval, double *Aval) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6), nw = gridDim.x * (TB / 64);
+  for (int r = w; r < c.n + c.m; r += nw) {
+    if (r < c.n) {
+      const int j = r, sp = c.M.split[j];
+      const double dj = dn[j];
+      for (int k = c.M.rowptr[j] + lane; k < c.M.rowptr[j + 1]; k += 64) {
+        const int cc = c.M.col[k];
+        // P(j,cc): row factor of the stored entry, then column factor; A'(j, n+i): E_i then D_j
+        if (k < sp) {
+          // the stored triu entry has row = min(j,cc), column = max(j,cc)
+          const double fr = j < cc ? dj : dn[cc], fc = j < cc ? dn[cc] : dj;
+          Mval[k] = (Mval[k] * fr) * fc;
+        } else Mval[k] = (Mval[k] * en[cc - c.n]) * dj;
+      }
+      if (lane == 0) { c.q[j] = c.q[j] * dj; c.D[j] = dj * c.D[j]; }
+    } else {
+      const int i = r - c.n;
+      const double ei = en[i];
+      for (int k = c.A.rowptr[i] + lane; k < c.A.rowptr[i + 1]; k += 64) Aval[k] = (Aval[k] * ei) * dn[c.A.col[k]];
+      if (lane == 0) c.E[i] = ei * c.E[i];
+    }
+  }
+}
+
+// cost normalisation, step 1: per-workgroup partial sums of the P column norms, max |q|
+__global__ void __launch_bounds__(TB) k_ruiz_cost_norms(Ctx c) {
+  __shared__ double red[16];
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6), nw = gridDim.x * (TB / 64);
+  double acc = 0.0, qm = 0.0;
+  for (int j = w; j < c.n; j += nw) {
+    double mx = 0.0;
+    for (int k = c.M.rowptr[j] + lane; k < c.M.split[j]; k += 64) mx = fmax(mx, fabs(c.M.val[k]));
+    mx = wave_max(mx);
+    if (lane == 0) { acc += mx; qm = fmax(qm, fabs(c.q[j])); }
+  }
+  acc = block_sum(acc, red);
+  block_max_to(qm, c.scal + SCI(SC_QDX), red);      // reuse a slot: max |q|
+  if (threadIdx.x == 0) c.part_s0[blockIdx.x] = acc;
+}
+
+// step 2 (one workgroup): c_t = 1 / clip(max(mean colnorm, clip(|q|_inf))), c *= c_t
+__global__ void __launch_bounds__(TB) k_ruiz_cost_scalar(Ctx c, int nparts) {
+  __shared__ double red[16];
+  double s[1];
+  reduce_parts<1>(c.part_s0, nullptr, nullptr, nparts, red, s);
+  if (threadIdx.x == 0) {
+    const double mean = s[0] / (double)c.n;
+    double ct = fmax(mean, clip_scaling(c.scal[SCI(SC_QDX)]));
+    ct = 1.0 / clip_scaling(ct);
+    c.scal[SCI(SC_OBJ)] = ct;                          // this pass's factor
+    c.scal[SCI(SC_DYLHS)] = c.scal[SCI(SC_DYLHS)] * ct;  // accumulated c
+    c.scal[SCI(SC_QDX)] = 0.0;
+  }
+}
+
+// step 3: P <- c_t P, q <- c_t q
+__global__ void __launch_bounds__(TB) k_ruiz_cost_apply(Ctx c, double *Mval) {
+  const double ct = c.scal[SCI(SC_OBJ)];
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6), nw = gridDim.x * (TB / 64);
+  for (int j = w; j < c.n; j += nw) {
+    for (int k = c.M.rowptr[j] + lane; k < c.M.split[j]; k += 64) Mval[k] *= ct;
+    if (lane == 0) c.q[j] *= ct;
+  }
+}
+
+// finish: l, u <- E l, E u ; Dinv, Einv
+__global__ void __launch_bounds__(TB) k_ruiz_finish(Ctx c) {
+  for (int i = blockIdx.x * TB + threadIdx.x; i < c.m; i += gridDim.x * TB) {
+    const double e = c.E[i];
+    c.l[i] = c.l[i] * e; c.u[i] = c.u[i] * e; c.Einv[i] = 1.0 / e;
+  }
+  for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) c.Dinv[j] = 1.0 / c.D[j];
+}
+
+__global__ void __launch_bounds__(TB) k_fill(double *p, double v, int cnt) {
+  for (int i = blockIdx.x * TB + threadIdx.x; i < cnt; i += gridDim.x * TB) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 struct HostMat {         // host image of a device CSR matrix
@@ -1039,6 +1159,8 @@ struct hipeng {
   bool split = false;     // large A: vector update and operator apply as two launches (plain 8-byte gathers)
   int rlA = 8, rlM = 8;   // lanes per row segment in the PCG kernels
   bool calibrated = false;
+  int warm_windows = 0;   // windows since the last (re)calibration: bursts grow 1, 4, 8, then up to 64
+  bool trace = false;
   hipeng_stats stats{};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   long long admm_done_seen = 0;
@@ -1241,6 +1363,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   {
     const char *v = getenv("OSQP_AMD_PCG_VARIANT");
     e->variant = v ? atoi(v) : 1;          // 1 = Chronopoulos-Gear (2 kernels / iteration), 0 = classic (3)
+    e->trace = getenv("OSQP_AMD_TRACE") != nullptr;
   }
   c.big = 0;   // experimental (OSQP_AMD_BIG=1): measured slower than the capped grid on config 3
   if (const char *bg = getenv("OSQP_AMD_BIG")) c.big = (atoi(bg) != 0 && e->variant == 1) ? 1 : 0;
@@ -1254,7 +1377,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   DA(dxy, n + m); DA(dy, m); DA(cvec, n);
   DA(pdir, n); DA(ut, n + m); DA(g4, 2 * n);
   DA(D, n); DA(Dinv, n); DA(E, m); DA(Einv, m);
-  const int np = std::max(c.gridM, c.gridA);
+  const int np = std::max(std::max(c.gridM, c.gridA), 2048);   // also scratch for the scaling kernels
   DA(part_rz, np); DA(part_rr, np); DA(part_bb, np); DA(part_pkp, np);
   DA(part_s0, np); DA(part_s1, np); DA(part_s2, np); DA(part_gam, np); DA(part_del, np);
   DA(scal, SC_COUNT * 16);
@@ -1270,7 +1393,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   e->prm.sigma = prm->sigma; e->prm.alpha = prm->alpha;
   e->prm.eps_rel = prm->pcg_eps_rel; e->prm.eps_abs = prm->pcg_eps_abs;
   e->prm.pcg_max_iter = (int)prm->pcg_max_iter; e->prm.cinv = 1.0;
-  e->prm.use_cvec = 0; e->prm.has_scaling = 0;
+  e->prm.use_cvec = 0; e->prm.has_scaling = 0; e->prm.k_expect = 1 << 30;
   if (push_params(e)) return HIPENG_ERR_HIP;
   if (upload_vec(e, c.q, q, n) || upload_vec(e, c.l, l, m) || upload_vec(e, c.u, u, m) ||
       upload_vec(e, c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
@@ -1328,6 +1451,53 @@ extern "C" int hipeng_set_scaling(hipeng *e, const c_float *D, const c_float *E,
     e->prm.has_scaling = 0; e->prm.cinv = 1.0;
     if (push_params(e)) return HIPENG_ERR_HIP;
   }
+  return 0;
+}
+
+// Ruiz equilibration of the resident (raw) problem, `passes` sweeps, entirely on the
+// device; afterwards the scaled q, l, u, the matrix values (triu(P) and A in the caller's
+// CSC order) and D, E, c are copied back for the host mirrors of the workspace.
+extern "C" int hipeng_ruiz_scale(hipeng *e, c_int passes, c_float *D, c_float *E, c_float *cost,
+                                 c_float *q, c_float *l, c_float *u, c_float *Px, c_float *Ax) {
+  if (!e || passes < 0) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  const Ctx &c = e->c;
+  const int n = e->n, m = e->m;
+  double *dn = c.kp, *en = c.dy;                 // scratch vectors of length n and m
+  const int gw = std::max(1, std::min(2048, (n + m + 3) / 4));
+  const int gn = std::max(1, std::min(1024, (n + 3) / 4));
+  HIPCHK(hipMemsetAsync(c.scal, 0, SC_COUNT * 16 * sizeof(double), e->stream));
+  hipLaunchKernelGGL(k_fill, dim3(elem_grid(n)), dim3(TB), 0, e->stream, c.D, 1.0, n);
+  hipLaunchKernelGGL(k_fill, dim3(elem_grid(std::max(m, 1))), dim3(TB), 0, e->stream, c.E, 1.0, m);
+  hipLaunchKernelGGL(k_fill, dim3(1), dim3(TB), 0, e->stream, c.scal + SCI(SC_DYLHS), 1.0, 1);
+  for (c_int p = 0; p < passes; p++) {
+    hipLaunchKernelGGL(k_ruiz_norms, dim3(gw), dim3(TB), 0, e->stream, c, dn, en);
+    hipLaunchKernelGGL(k_ruiz_apply, dim3(gw), dim3(TB), 0, e->stream, c, dn, en, e->M.d_val, e->A.d_val);
+    hipLaunchKernelGGL(k_ruiz_cost_norms, dim3(gn), dim3(TB), 0, e->stream, c);
+    hipLaunchKernelGGL(k_ruiz_cost_scalar, dim3(1), dim3(TB), 0, e->stream, c, gn);
+    hipLaunchKernelGGL(k_ruiz_cost_apply, dim3(gn), dim3(TB), 0, e->stream, c, e->M.d_val);
+  }
+  hipLaunchKernelGGL(k_ruiz_finish, dim3(elem_grid(std::max(n, m))), dim3(TB), 0, e->stream, c);
+  HIPCHK(hipGetLastError());
+  // host mirrors
+  double cc = 1.0;
+  HIPCHK(hipMemcpyAsync(&cc, c.scal + SCI(SC_DYLHS), sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->M.val.data(), e->M.d_val, e->M.val.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (D) HIPCHK(hipMemcpyAsync(D, c.D, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (E && m) HIPCHK(hipMemcpyAsync(E, c.E, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (q) HIPCHK(hipMemcpyAsync(q, c.q, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (l && m) HIPCHK(hipMemcpyAsync(l, c.l, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (u && m) HIPCHK(hipMemcpyAsync(u, c.u, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (cost) *cost = cc;
+  if (Px) for (size_t k = 0; k < e->P_toM_up.size(); k++) Px[k] = e->M.val[e->P_toM_up[k]];
+  if (Ax) for (size_t k = 0; k < e->A_toM.size(); k++) Ax[k] = e->M.val[e->A_toM[k]];
+  for (size_t k = 0; k < e->A_toM.size(); k++) e->A.val[e->A_csc2csr[k]] = e->M.val[e->A_toM[k]];
+  for (int j = 0; j < n; j++) e->pdiag[j] = 0.0;
+  for (size_t k = 0; k < e->P_toM_up.size(); k++) if (e->P_toM_lo[k] < 0) e->pdiag[e->M.col[e->P_toM_up[k]]] = e->M.val[e->P_toM_up[k]];
+  if (upload_vec(e, c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
+  e->prm.has_scaling = passes > 0 ? 1 : 0; e->prm.cinv = 1.0 / cc;
+  if (push_params(e)) return HIPENG_ERR_HIP;
   return 0;
 }
 
@@ -1394,6 +1564,21 @@ extern "C" int hipeng_upload_matrices(hipeng *e, const csc *P, const csc *A) {
   return 0;
 }
 
+// The resident matrix values changed in place (device-side rescaling): rebuild what depends
+// on them -- Jacobi preconditioner, z~ = A x~ and the m-parts of the PCG input vectors.
+extern "C" int hipeng_matrices_changed(hipeng *e) {
+  if (!e) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
+  if (e->m > 0) {
+    hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, e->c.va, e->c.zt, 0);
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
 extern "C" int hipeng_cold_start(hipeng *e) {
   if (!e) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
@@ -1403,6 +1588,7 @@ extern "C" int hipeng_cold_start(hipeng *e) {
   HIPCHK(hipMemsetAsync(e->c.vb, 0, std::max<size_t>(nm, 8), e->stream));
   HIPCHK(hipMemsetAsync(e->c.z, 0, std::max<size_t>(e->m, 1) * sizeof(double), e->stream));
   HIPCHK(hipMemsetAsync(e->c.zt, 0, std::max<size_t>(e->m, 1) * sizeof(double), e->stream));
+  e->calibrated = false;   // the first solve from zero needs far more PCG iterations than the steady state
   return 0;
 }
 
@@ -1498,8 +1684,9 @@ static int read_state(hipeng *e, State *s) {
 }
 
 static int next_K(int want, int cap) {
+  // even unroll counts: step 2 up to 32, step 4 up to 96, then +25 %
   int K = 2;
-  while (K < want) K = (K < 16) ? K + 2 : (K < 64 ? K + 8 : K * 2);
+  while (K < want) K = (K < 32) ? K + 2 : (K < 96 ? K + 4 : ((K + K / 4 + 1) & ~1));
   if (K > cap) K = std::max(2, (cap + 1) & ~1);
   return K;
 }
@@ -1520,26 +1707,35 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   while (remaining > 0) {
     hipGraphExec_t ge;
     if (get_graph(e, e->K, false, &ge)) return HIPENG_ERR_HIP;
-    const long long burst = e->calibrated ? std::min<long long>(remaining, 64) : 1;
-    e->calibrated = true;
+    if (!e->calibrated) { e->warm_windows = 0; e->calibrated = true; }
+    static const int ramp[] = {1, 4, 8};
+    const long long burst = std::min<long long>(remaining, e->warm_windows < 3 ? ramp[e->warm_windows] : 64);
+    e->warm_windows++;
     for (long long i = 0; i < burst; i++) HIPCHK(hipGraphLaunch(ge, e->stream));
     e->stats.graph_launches += (c_int)burst;
     if (read_state(e, &s)) return HIPENG_ERR_HIP;
     while (s.stalled) {            // finish the stalled solve with more PCG iterations
       hipGraphExec_t gc;
-      const int Kc = next_K(std::max(e->K, 4), cap);
+      const int Kc = next_K(std::max(2 * e->K, 16), cap);
       if (get_graph(e, Kc, true, &gc)) return HIPENG_ERR_HIP;
       HIPCHK(hipGraphLaunch(gc, e->stream));
       e->stats.graph_launches += 1;
       if (read_state(e, &s)) return HIPENG_ERR_HIP;
+      if (e->trace) fprintf(stderr, "[osqp_amd]   stall: continue graph Kc=%d -> iters %d stalled=%d\n", Kc, std::max(s.iters[0], s.iters[1]), s.stalled);
       e->K = next_K(std::max(e->K + 2, (int)(1.5 * std::max(s.iters[0], s.iters[1])) + 2), cap);
       if (++guard > 100000) { fprintf(stderr, "osqp_amd: PCG continuation did not terminate\n"); return HIPENG_ERR_HIP; }
     }
     remaining = count - (s.admm_done - start);
+    if (e->trace) fprintf(stderr, "[osqp_amd] window: K=%d burst=%lld done=%lld iters_max=%d last=%d launches=%lld\n", e->K, burst, (long long)(s.admm_done - start), s.iters_max, s.iters_last, (long long)e->stats.graph_launches);
     // track the iteration count: shrink slowly, grow at once
-    const int want = (int)(1.25 * s.iters_max) + 2;
+    const int want = s.iters_max + std::max(3, s.iters_max / 6);   // head-room against drift between windows
     const int Kn = next_K(want, cap);
-    if (Kn > e->K || Kn < e->K - 4 || (Kn < e->K && e->K <= 16)) e->K = Kn;
+    e->K = Kn;
+    if (std::abs(e->prm.k_expect - s.iters_max) > 1) {
+      e->prm.k_expect = s.iters_max;
+      HIPCHK(hipMemcpyAsync(e->d_prm, &e->prm, sizeof(Params), hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+    }
     if (++guard > 1000000) return HIPENG_ERR_HIP;
   }
   e->stats.admm_done = (c_int)(s.admm_done - start);
@@ -1548,6 +1744,21 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   e->stats.pcg_iters_max = s.iters_max;
   e->stats.pcg_forced = s.forced;
   e->stats.neg_curvature = s.neg_curv_seen;
+  return 0;
+}
+
+extern "C" int hipeng_reset_stats(hipeng *e) {
+  if (!e) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  State s;
+  if (read_state(e, &s)) return HIPENG_ERR_HIP;
+  s.forced = 0; s.iters_total = 0; s.iters_max = 0; s.iters_last = 0; s.neg_curv_seen = 0; s.neg_curv = 0;
+  HIPCHK(hipMemcpyAsync(e->c.st, &s, sizeof(State), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->stats = hipeng_stats{};
+  e->stats.kernels_per_pcg_iter = e->variant == 1 ? 2 : 3;
+  e->calibrated = false;
+  e->K = 8;
   return 0;
 }
 

@@ -88,6 +88,8 @@ typedef struct {
   c_int n, m, polish;
   c_float sigma;
   c_float *rho_tmp;       /* polish: constant 1/delta vector                      */
+  csc *rawP, *rawA;       /* workspace view: unscaled problem as last given by the caller */
+  c_float *rawq, *rawl, *rawu;
   hipeng_scalars sc;      /* last residual scalars                                */
   c_int sc_iter;          /* iteration they belong to (-1 = stale)                */
   c_int host_syncs;
@@ -129,6 +131,9 @@ static void pcg_free(LinSysSolver *self) {
   hipeng_destroy(s->eng);
   hipeng_destroy(s->aux);
   free(s->rho_tmp);
+  if (s->rawP) { free(s->rawP->p); free(s->rawP->i); free(s->rawP->x); free(s->rawP); }
+  if (s->rawA) { free(s->rawA->p); free(s->rawA->i); free(s->rawA->x); free(s->rawA); }
+  free(s->rawq); free(s->rawl); free(s->rawu);
   free(s);
 }
 
@@ -331,97 +336,11 @@ static c_int check_settings(const OSQPSettings *s) {   /* src/auxil.c:893-1065 *
 }
 
 /* ------------------------------------------------------------------------ */
-/* Ruiz equilibration on the host copy of the data (src/scaling.c:7-175)      */
+/* Ruiz equilibration runs on the device (hipeng_ruiz_scale); the host keeps   */
+/* the mirrors the API exposes (work->data, work->scaling)                     */
 /* ------------------------------------------------------------------------ */
-static void clip_scale(c_float *v, c_int n) {
-  for (c_int k = 0; k < n; k++) {
-    if (v[k] < MIN_SCALING) v[k] = 1.0;
-    if (v[k] > MAX_SCALING) v[k] = MAX_SCALING;
-  }
-}
-
-static void sym_col_norms(const csc *P, c_float *out) {
-  for (c_int j = 0; j < P->n; j++) out[j] = 0.0;
-  for (c_int j = 0; j < P->n; j++)
-    for (c_int k = P->p[j]; k < P->p[j + 1]; k++) {
-      c_float a = fabs(P->x[k]);
-      c_int i = P->i[k];
-      if (a > out[j]) out[j] = a;
-      if (i != j && a > out[i]) out[i] = a;
-    }
-}
-
-static void equilibrate(OSQPWorkspace *w) {
-  c_int n = w->data->n, m = w->data->m;
-  csc *P = w->data->P, *A = w->data->A;
-  c_float *q = w->data->q, *D = w->scaling->D, *E = w->scaling->E;
-  c_float *dn = w->D_temp, *da = w->D_temp_A, *en = w->E_temp;
-  w->scaling->c = 1.0;
-  for (c_int j = 0; j < n; j++) D[j] = 1.0;
-  for (c_int i = 0; i < m; i++) E[i] = 1.0;
-  for (c_int pass = 0; pass < w->settings->scaling; pass++) {
-    sym_col_norms(P, dn);
-    for (c_int i = 0; i < m; i++) en[i] = 0.0;
-    for (c_int j = 0; j < n; j++) {
-      c_float cmax = 0.0;
-      for (c_int k = A->p[j]; k < A->p[j + 1]; k++) {
-        c_float a = fabs(A->x[k]);
-        if (a > cmax) cmax = a;
-        if (a > en[A->i[k]]) en[A->i[k]] = a;
-      }
-      da[j] = cmax;
-      if (cmax > dn[j]) dn[j] = cmax;
-    }
-    clip_scale(dn, n); clip_scale(en, m);
-    for (c_int j = 0; j < n; j++) dn[j] = (c_float)1.0 / sqrt(dn[j]);
-    for (c_int i = 0; i < m; i++) en[i] = (c_float)1.0 / sqrt(en[i]);
-    /* P <- D P D (row factor first, then column factor), A <- E A D, q <- D q */
-    for (c_int j = 0; j < n; j++)
-      for (c_int k = P->p[j]; k < P->p[j + 1]; k++) { P->x[k] *= dn[P->i[k]]; }
-    for (c_int j = 0; j < n; j++)
-      for (c_int k = P->p[j]; k < P->p[j + 1]; k++) { P->x[k] *= dn[j]; }
-    for (c_int j = 0; j < n; j++)
-      for (c_int k = A->p[j]; k < A->p[j + 1]; k++) { A->x[k] *= en[A->i[k]]; }
-    for (c_int j = 0; j < n; j++)
-      for (c_int k = A->p[j]; k < A->p[j + 1]; k++) { A->x[k] *= dn[j]; }
-    for (c_int j = 0; j < n; j++) { q[j] = q[j] * dn[j]; D[j] = dn[j] * D[j]; }
-    for (c_int i = 0; i < m; i++) E[i] = en[i] * E[i];
-    /* cost normalisation */
-    sym_col_norms(P, dn);
-    c_float mean = 0.0;
-    for (c_int j = 0; j < n; j++) mean += dn[j];
-    mean /= (c_float)n;
-    c_float qn = absmax(q, n);
-    clip_scale(&qn, 1);
-    c_float ct = HMAX(mean, qn);
-    clip_scale(&ct, 1);
-    ct = 1. / ct;
-    for (c_int k = 0; k < P->p[n]; k++) P->x[k] *= ct;
-    for (c_int j = 0; j < n; j++) q[j] *= ct;
-    w->scaling->c *= ct;
-  }
-  w->scaling->cinv = 1. / w->scaling->c;
-  for (c_int j = 0; j < n; j++) w->scaling->Dinv[j] = (c_float)1.0 / D[j];
-  for (c_int i = 0; i < m; i++) w->scaling->Einv[i] = (c_float)1.0 / E[i];
-  for (c_int i = 0; i < m; i++) { w->data->l[i] = w->data->l[i] * E[i]; w->data->u[i] = w->data->u[i] * E[i]; }
-}
-
-static void unequilibrate(OSQPWorkspace *w) {   /* src/scaling.c:160-175 */
-  c_int n = w->data->n, m = w->data->m;
-  csc *P = w->data->P, *A = w->data->A;
-  const OSQPScaling *s = w->scaling;
-  for (c_int k = 0; k < P->p[n]; k++) P->x[k] *= s->cinv;
-  for (c_int j = 0; j < n; j++)
-    for (c_int k = P->p[j]; k < P->p[j + 1]; k++) P->x[k] *= s->Dinv[P->i[k]];
-  for (c_int j = 0; j < n; j++)
-    for (c_int k = P->p[j]; k < P->p[j + 1]; k++) P->x[k] *= s->Dinv[j];
-  for (c_int j = 0; j < n; j++) { w->data->q[j] *= s->cinv; w->data->q[j] = w->data->q[j] * s->Dinv[j]; }
-  for (c_int j = 0; j < n; j++)
-    for (c_int k = A->p[j]; k < A->p[j + 1]; k++) A->x[k] *= s->Einv[A->i[k]];
-  for (c_int j = 0; j < n; j++)
-    for (c_int k = A->p[j]; k < A->p[j + 1]; k++) A->x[k] *= s->Dinv[j];
-  for (c_int i = 0; i < m; i++) { w->data->l[i] = w->data->l[i] * s->Einv[i]; w->data->u[i] = w->data->u[i] * s->Einv[i]; }
-}
+#define PCG_OF(w) ((hip_pcg_solver *)((w)->linsys_solver))
+static c_int rescale_on_device(OSQPWorkspace *w);
 
 /* ------------------------------------------------------------------------ */
 /* rho by constraint class (src/auxil.c:76-142)                               */
@@ -455,6 +374,19 @@ static c_int reclassify_rows(OSQPWorkspace *w) {
     changed = 1;
   }
   if (changed) return w->linsys_solver->update_rho_vec(w->linsys_solver, w->rho_vec);
+  return 0;
+}
+
+/* The device holds the raw problem; equilibrate it there and refresh the host mirrors
+ * (scaled P, A, q, l, u and D, E, c) -- scale_data of src/scaling.c:44-156. */
+static c_int rescale_on_device(OSQPWorkspace *w) {
+  hip_pcg_solver *s = PCG_OF(w);
+  const c_int n = w->data->n, m = w->data->m;
+  if (hipeng_ruiz_scale(s->eng, w->settings->scaling, w->scaling->D, w->scaling->E, &w->scaling->c,
+                        w->data->q, w->data->l, w->data->u, w->data->P->x, w->data->A->x)) return 1;
+  w->scaling->cinv = 1. / w->scaling->c;
+  for (c_int j = 0; j < n; j++) w->scaling->Dinv[j] = (c_float)1.0 / w->scaling->D[j];
+  for (c_int i = 0; i < m; i++) w->scaling->Einv[i] = (c_float)1.0 / w->scaling->E[i];
   return 0;
 }
 
@@ -526,24 +458,33 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
     if (!w->scaling->D || !w->scaling->Dinv || !w->scaling->E || !w->scaling->Einv ||
         !w->D_temp || !w->D_temp_A || !w->E_temp)
       return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
-    equilibrate(w);
   }
-  init_rho_vec(w);
 
-  /* device engine = the workspace's linear-system plugin */
+  /* device engine = the workspace's linear-system plugin; it is created on the RAW problem and
+   * equilibrates it in place on the GPU (scale_data, src/scaling.c:44-156) */
   hip_pcg_solver *s = pcg_alloc(n, m, w->settings->sigma, 0);
   if (!s) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
   s->owner = w;
   w->linsys_solver = (LinSysSolver *)s;
+  if (settings->scaling) {
+    s->rawP = dup_csc(data->P); s->rawA = dup_csc(data->A);
+    s->rawq = dup_vec(data->q, n); s->rawl = dup_vec(data->l, m); s->rawu = dup_vec(data->u, m);
+    if (!s->rawP || !s->rawA || !s->rawq || !s->rawl || !s->rawu)
+      return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
+  }
   hipeng_params prm;
   fill_params(&prm, w->settings->sigma, w->settings->alpha, n);
   opt_init();
   int rc = hipeng_create(&s->eng, w->data->P, w->data->A, w->data->q, w->data->l, w->data->u,
-                         w->rho_vec, &prm, (int)g_opt.device);
+                         NULL, &prm, (int)g_opt.device);
   if (rc == HIPENG_ERR_NO_DEVICE)
     return setup_fail(OSQP_LINSYS_SOLVER_LOAD_ERROR, "no HIP device: the HIP PCG solver cannot be loaded");
   if (rc) return setup_fail(OSQP_LINSYS_SOLVER_INIT_ERROR, "HIP engine initialisation failed");
-  if (w->scaling) hipeng_set_scaling(s->eng, w->scaling->D, w->scaling->E, w->scaling->c);
+  if (settings->scaling && rescale_on_device(w))
+    return setup_fail(OSQP_LINSYS_SOLVER_INIT_ERROR, "HIP engine initialisation failed");
+  init_rho_vec(w);
+  if (hipeng_upload_rho(s->eng, w->rho_vec))
+    return setup_fail(OSQP_LINSYS_SOLVER_INIT_ERROR, "HIP engine initialisation failed");
   /* Convexity probe.  The reference rejects a KKT matrix whose LDL^T factor has fewer than n
    * positive pivots (qdldl_interface.c:93-99, OSQP_NONCVX_ERROR), i.e. a reduced matrix
    * P + sigma I + A' rho A that is not positive definite.  An iterative solver has no inertia;
@@ -568,6 +509,7 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
       return setup_fail(OSQP_NONCVX_ERROR, "KKT matrix factorization.\nThe problem seems to be non-convex");
     hipeng_set_params(s->eng, &prm);
     hipeng_cold_start(s->eng);
+    hipeng_reset_stats(s->eng);
   }
 
   w->info->status_polish = 0;
@@ -870,6 +812,7 @@ c_int osqp_update_lin_cost(OSQPWorkspace *w, const c_float *q_new) {
   const c_int n = w->data->n;
   memcpy(w->data->q, q_new, (size_t)n * sizeof(c_float));
   if (w->settings->scaling) {
+    memcpy(PCG(w)->rawq, q_new, (size_t)n * sizeof(c_float));
     for (c_int j = 0; j < n; j++) w->data->q[j] = w->data->q[j] * w->scaling->D[j];
     for (c_int j = 0; j < n; j++) w->data->q[j] *= w->scaling->c;
   }
@@ -893,6 +836,7 @@ c_int osqp_update_bounds(OSQPWorkspace *w, const c_float *l_new, const c_float *
     if (l_new[i] > u_new[i]) { fprintf(stderr, "ERROR in osqp_update_bounds: lower bound must be lower than or equal to upper bound\n"); return 1; }
   memcpy(w->data->l, l_new, (size_t)m * sizeof(c_float));
   memcpy(w->data->u, u_new, (size_t)m * sizeof(c_float));
+  if (w->settings->scaling) { memcpy(PCG(w)->rawl, l_new, (size_t)m * sizeof(c_float)); memcpy(PCG(w)->rawu, u_new, (size_t)m * sizeof(c_float)); }
   if (w->settings->scaling)
     for (c_int i = 0; i < m; i++) { w->data->l[i] = w->data->l[i] * w->scaling->E[i]; w->data->u[i] = w->data->u[i] * w->scaling->E[i]; }
   c_int rc = push_bounds(w);
@@ -905,6 +849,7 @@ c_int osqp_update_lower_bound(OSQPWorkspace *w, const c_float *l_new) {
   upd_begin(w);
   const c_int m = w->data->m;
   memcpy(w->data->l, l_new, (size_t)m * sizeof(c_float));
+  if (w->settings->scaling) memcpy(PCG(w)->rawl, l_new, (size_t)m * sizeof(c_float));
   if (w->settings->scaling) for (c_int i = 0; i < m; i++) w->data->l[i] = w->data->l[i] * w->scaling->E[i];
   for (c_int i = 0; i < m; i++)
     if (w->data->l[i] > w->data->u[i]) { fprintf(stderr, "ERROR in osqp_update_lower_bound: upper bound must be greater than or equal to lower bound\n"); return 1; }
@@ -918,6 +863,7 @@ c_int osqp_update_upper_bound(OSQPWorkspace *w, const c_float *u_new) {
   upd_begin(w);
   const c_int m = w->data->m;
   memcpy(w->data->u, u_new, (size_t)m * sizeof(c_float));
+  if (w->settings->scaling) memcpy(PCG(w)->rawu, u_new, (size_t)m * sizeof(c_float));
   if (w->settings->scaling) for (c_int i = 0; i < m; i++) w->data->u[i] = w->data->u[i] * w->scaling->E[i];
   for (c_int i = 0; i < m; i++)
     if (w->data->u[i] < w->data->l[i]) { fprintf(stderr, "ERROR in osqp_update_upper_bound: lower bound must be lower than or equal to upper bound\n"); return 1; }
@@ -949,26 +895,35 @@ c_int osqp_warm_start_y(OSQPWorkspace *w, const c_float *y) { NEED_WORK(w); retu
 
 static c_int patch(OSQPWorkspace *w, const c_float *Px, const c_int *Pi, c_int Pn, int doP,
                    const c_float *Ax, const c_int *Ai, c_int An, int doA) {
+  hip_pcg_solver *s = PCG(w);
   const c_int nnzP = w->data->P->p[w->data->P->n], nnzA = w->data->A->p[w->data->A->n];
   upd_begin(w);
   if (doP && Pi && Pn > nnzP) { fprintf(stderr, "ERROR: new number of elements greater than elements in P\n"); return 1; }
   if (doA && Ai && An > nnzA) { fprintf(stderr, "ERROR: new number of elements greater than elements in A\n"); return doP ? 2 : 1; }
-  if (w->settings->scaling) unequilibrate(w);
+  /* The reference unscales, patches and re-equilibrates from scratch (osqp.c:1046-1067).  Here
+   * the unscaled problem is kept as given, patched, uploaded and re-equilibrated on the GPU. */
+  csc *P = w->settings->scaling ? s->rawP : w->data->P;
+  csc *A = w->settings->scaling ? s->rawA : w->data->A;
   if (doP) {
-    if (Pi) for (c_int k = 0; k < Pn; k++) w->data->P->x[Pi[k]] = Px[k];
-    else    for (c_int k = 0; k < nnzP; k++) w->data->P->x[k] = Px[k];
+    if (Pi) for (c_int k = 0; k < Pn; k++) P->x[Pi[k]] = Px[k];
+    else    for (c_int k = 0; k < nnzP; k++) P->x[k] = Px[k];
   }
   if (doA) {
-    if (Ai) for (c_int k = 0; k < An; k++) w->data->A->x[Ai[k]] = Ax[k];
-    else    for (c_int k = 0; k < nnzA; k++) w->data->A->x[k] = Ax[k];
+    if (Ai) for (c_int k = 0; k < An; k++) A->x[Ai[k]] = Ax[k];
+    else    for (c_int k = 0; k < nnzA; k++) A->x[k] = Ax[k];
   }
-  hipeng *e = PCG(w)->eng;
+  c_int rc;
   if (w->settings->scaling) {
-    equilibrate(w);   /* also rescales q, l, u: all of them go back to the device */
-    if (hipeng_set_scaling(e, w->scaling->D, w->scaling->E, w->scaling->c) ||
-        hipeng_upload_q(e, w->data->q) || hipeng_upload_bounds(e, w->data->l, w->data->u)) return 1;
+    if (hipeng_upload_matrices(s->eng, P, A) || hipeng_upload_q(s->eng, s->rawq) ||
+        hipeng_upload_bounds(s->eng, s->rawl, s->rawu) || rescale_on_device(w)) return 1;
+    rc = hipeng_matrices_changed(s->eng) ? 1 : 0;
+    if (s->aux && hipeng_upload_matrices(s->aux, w->data->P, w->data->A)) rc = 1;
+    s->sc_iter = -1;
+    /* constraint classes follow the rescaled bounds (set_rho_vec semantics are unchanged:
+     * classes depend on l, u only through the 1e26 / RHO_TOL tests) */
+  } else {
+    rc = w->linsys_solver->update_matrices(w->linsys_solver, w->data->P, w->data->A);
   }
-  c_int rc = w->linsys_solver->update_matrices(w->linsys_solver, w->data->P, w->data->A);
   info_reset(w->info);
   upd_end(w);
   return rc;

@@ -59,7 +59,9 @@ def test_spmv_golden_lin_alg(gpu_lib):
     d = load_golden("lin_alg")
     A, Pu, x, y = d["test_mat_vec_A"], d["test_mat_vec_Pu"], d["test_mat_vec_x"], d["test_mat_vec_y"]
     m, n = A.shape
-    s = osqp_amd.OSQP().setup(P=Pu, q=np.zeros(n), A=A, l=-np.ones(m), u=np.ones(m), scaling=0)
+    # the fixture's P is a random symmetric (indefinite) matrix: a large sigma keeps the
+    # reduced matrix positive definite so that setup's convexity probe accepts it
+    s = osqp_amd.OSQP().setup(P=Pu, q=np.zeros(n), A=A, l=-np.ones(m), u=np.ones(m), scaling=0, sigma=100.0)
     assert np.abs(_engine_spmv(s, 0, x, m) - d["test_mat_vec_Ax"]).max() < 1e-14
     assert np.abs(_engine_spmv(s, 1, y, n) - d["test_mat_vec_ATy"]).max() < 1e-14
     assert np.abs(_engine_spmv(s, 2, x, n) - d["test_mat_vec_Px"]).max() < 1e-14
