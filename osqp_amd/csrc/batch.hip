@@ -416,18 +416,23 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
   __syncthreads();
   tstamp[3] = wall_clock64();
   bool kinv_dirty = false;
+  // refinement is applied only to QPs whose K^-1 left a relative residual above 1e-10 in the
+  // first solve after it was (re)built; the verdict is kept in bit 1 of flag[]
+  const int qflag = phase == 0 ? 1 : io.flag[qp];
+  bool need_refine = (qflag & 2) != 0, check_pending = false;
   double *Wk = io.Wk + qp * (long long)(NP * NP);
-  if (phase == 0 || io.flag[qp]) {
+  if (phase == 0 || (qflag & 1)) {
     form_K<TR, TC, GC>(a, n, s, st.sigma);
     tstamp[4] = wall_clock64();
     invert_tiles<TR, TC, GC>(a, s, n);
-    kinv_dirty = true;
+    kinv_dirty = true; check_pending = true;
   } else {
 #pragma unroll
     for (int r = 0; r < TR; ++r)
 #pragma unroll
       for (int c = 0; c < TC; ++c) a[r][c] = Wk[(r * TC + c) * NT + tid];
     tstamp[4] = wall_clock64();
+    if (qflag & 4) check_pending = true;
   }
   tstamp[5] = wall_clock64();
   if (phase == 0) {
@@ -444,7 +449,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
     for (int r = 0; r < TR; ++r)
 #pragma unroll
       for (int c = 0; c < TC; ++c) Wk[(r * TC + c) * NT + tid] = a[r][c];
-    if (tid == 0) { io.Wc[qp] = cs; io.rho_io[qp] = rho; io.flag[qp] = 0; }
+    if (tid == 0) { io.Wc[qp] = cs; io.rho_io[qp] = rho; io.flag[qp] = 4; }   // 4: verdict on refinement still open
     return;
   }
 
@@ -480,13 +485,21 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
       PSTAMP(0);
       tile_gemv<TR, TC, GC>(a, s_b, s_xt, s.gp);
       PSTAMP(1);
-      for (int r = 0; r < st.refine; ++r) {   // xt += Kinv (b - K xt)
+      if (st.refine && (need_refine || check_pending)) {   // xt += Kinv (b - K xt)
         for (int i = tid; i < m; i += NT) s_w[i] = s_rho[i] * a_row_dot(s, s_xt, i);
         __syncthreads();
-        for (int j = tid; j < NP; j += NT)
+        double rmax = 0.0, bmax = 0.0;
+        for (int j = tid; j < NP; j += NT) {
           s_tn[j] = j < n ? s_b[j] - (p_row_dot(s, s_xt, j) + sigma * s_xt[j] + a_col_dot(s, s_w, j)) : 0.0;
+          rmax = fmax(rmax, fabs(s_tn[j])); bmax = fmax(bmax, fabs(s_b[j]));
+        }
+        if (check_pending) {           // decide once per K^-1 whether refinement is needed at all
+          rmax = b_max<NW>(rmax, s.red); bmax = b_max<NW>(bmax, s.red);
+          need_refine = rmax > 1e-10 * bmax;
+          check_pending = false;
+        }
         __syncthreads();
-        tile_gemv<TR, TC, GC>(a, s_tn, s_dx, s.gp);        // dx is free until the x update below
+        tile_gemv<TR, TC, GC>(a, s_tn, s_dx, s.gp);   // dx is free until the x update below
         for (int j = tid; j < n; j += NT) s_xt[j] += s_dx[j];
         __syncthreads();
       }
@@ -656,7 +669,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
           __syncthreads();
           form_K<TR, TC, GC>(a, n, s, sigma);
           invert_tiles<TR, TC, GC>(a, s, n);
-          kinv_dirty = true;
+          kinv_dirty = true; check_pending = true;
         }
       }
       if (iter >= st.max_iter) stage = checked ? 2 : 1;
@@ -720,7 +733,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
       for (int c = 0; c < TC; ++c) Wk[(r * TC + c) * NT + tid] = a[r][c];
   }
   if (tid == 0) {
-    io.flag[qp] = 0;
+    io.flag[qp] = check_pending ? 4 : (need_refine ? 2 : 0);
     double *inf = io.info + qp * 8;
     inf[0] = iter; inf[1] = status; inf[2] = obj; inf[3] = pri_res; inf[4] = dua_res;
     inf[5] = rho_updates; inf[6] = rho_est; inf[7] = rho;
@@ -755,7 +768,7 @@ __global__ void __launch_bounds__(256) k_batch_update(int n, int m, BIO io, cons
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0 && changed) io.flag[qp] = 1;
+  if (threadIdx.x == 0 && changed) io.flag[qp] = 1;   // rebuild; the refinement verdict is re-taken after it
 }
 
 // ---------------------------------------------------------------------------
