@@ -95,6 +95,12 @@ typedef struct {
   c_int host_syncs;
 } osqp_amd_stats;
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, osqp_amd_stats *st);
+/* Binary problem files: one little-endian file per QP (layout in osqp_host.c); the data the
+ * reference's generators emit as C headers (tests/utils/codegen_utils.py:172-347).
+ * Return 0, or 1 bad argument / 2 cannot open / 3 malformed / 4 out of memory. */
+c_int osqp_amd_write_problem(const char *path, const OSQPData *data);
+c_int osqp_amd_read_problem(const char *path, OSQPData **data);
+void  osqp_amd_free_problem(OSQPData *data);
 /* Raw engine handle of a workspace (for the kernel-level tests / bench). */
 void *osqp_amd_engine(const OSQPWorkspace *work);
 

@@ -1110,6 +1110,75 @@ cleanup:
 }
 
 /* ------------------------------------------------------------------------ */
+/* binary problem files: the data the reference's     */
+/* generators emit as C headers (tests/utils/codegen_utils.py:172-347), as one */
+/* little-endian file: magic "OSQPAMD1", int64 n, m, nnzP, nnzA, then          */
+/* P.p[n+1] P.i[nnzP] (int64) P.x[nnzP] (f64), A.p A.i A.x, q[n] l[m] u[m].    */
+/* ------------------------------------------------------------------------ */
+static const char PROBLEM_MAGIC[8] = {'O', 'S', 'Q', 'P', 'A', 'M', 'D', '1'};
+
+c_int osqp_amd_write_problem(const char *path, const OSQPData *d) {
+  if (!path || check_data(d)) return 1;
+  FILE *f = fopen(path, "wb");
+  if (!f) return 2;
+  const c_int hdr[4] = {d->n, d->m, d->P->p[d->n], d->A->p[d->n]};
+  int ok = fwrite(PROBLEM_MAGIC, 1, 8, f) == 8 && fwrite(hdr, sizeof(c_int), 4, f) == 4;
+  const csc *M[2] = {d->P, d->A};
+  for (int k = 0; ok && k < 2; k++) {
+    const size_t nnz = (size_t)M[k]->p[d->n];
+    ok = fwrite(M[k]->p, sizeof(c_int), (size_t)d->n + 1, f) == (size_t)d->n + 1 &&
+         fwrite(M[k]->i, sizeof(c_int), nnz, f) == nnz && fwrite(M[k]->x, sizeof(c_float), nnz, f) == nnz;
+  }
+  ok = ok && fwrite(d->q, sizeof(c_float), (size_t)d->n, f) == (size_t)d->n &&
+       fwrite(d->l, sizeof(c_float), (size_t)d->m, f) == (size_t)d->m &&
+       fwrite(d->u, sizeof(c_float), (size_t)d->m, f) == (size_t)d->m;
+  fclose(f);
+  return ok ? 0 : 3;
+}
+
+void osqp_amd_free_problem(OSQPData *d) {
+  if (!d) return;
+  free_csc(d->P); free_csc(d->A);
+  free(d->q); free(d->l); free(d->u); free(d);
+}
+
+c_int osqp_amd_read_problem(const char *path, OSQPData **out) {
+  if (!path || !out) return 1;
+  *out = NULL;
+  FILE *f = fopen(path, "rb");
+  if (!f) return 2;
+  char magic[8];
+  c_int hdr[4];
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, PROBLEM_MAGIC, 8) || fread(hdr, sizeof(c_int), 4, f) != 4 ||
+      hdr[0] <= 0 || hdr[1] < 0 || hdr[2] < 0 || hdr[3] < 0) { fclose(f); return 3; }
+  OSQPData *d = (OSQPData *)calloc(1, sizeof(OSQPData));
+  if (!d) { fclose(f); return 4; }
+  d->n = hdr[0]; d->m = hdr[1];
+  int ok = 1;
+  for (int k = 0; ok && k < 2; k++) {
+    const c_int nnz = hdr[2 + k];
+    csc *M = (csc *)calloc(1, sizeof(csc));
+    if (!M) { ok = 0; break; }
+    if (k == 0) d->P = M; else d->A = M;
+    M->m = k == 0 ? d->n : d->m; M->n = d->n; M->nz = -1; M->nzmax = nnz > 0 ? nnz : 1;
+    M->p = (c_int *)malloc(((size_t)d->n + 1) * sizeof(c_int));
+    M->i = (c_int *)malloc((size_t)M->nzmax * sizeof(c_int));
+    M->x = (c_float *)malloc((size_t)M->nzmax * sizeof(c_float));
+    ok = M->p && M->i && M->x && fread(M->p, sizeof(c_int), (size_t)d->n + 1, f) == (size_t)d->n + 1 &&
+         fread(M->i, sizeof(c_int), (size_t)nnz, f) == (size_t)nnz &&
+         fread(M->x, sizeof(c_float), (size_t)nnz, f) == (size_t)nnz && M->p[d->n] == nnz;
+  }
+  d->q = zero_vec(d->n); d->l = zero_vec(d->m); d->u = zero_vec(d->m);
+  ok = ok && d->q && d->l && d->u && fread(d->q, sizeof(c_float), (size_t)d->n, f) == (size_t)d->n &&
+       fread(d->l, sizeof(c_float), (size_t)d->m, f) == (size_t)d->m &&
+       fread(d->u, sizeof(c_float), (size_t)d->m, f) == (size_t)d->m;
+  fclose(f);
+  if (!ok || check_data(d)) { osqp_amd_free_problem(d); return 3; }
+  *out = d;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* engine access for tests / bench                                            */
 /* ------------------------------------------------------------------------ */
 c_int osqp_amd_get_stats(const OSQPWorkspace *w, osqp_amd_stats *out) {

@@ -159,3 +159,34 @@ def test_sharded_batch_gather_gloo_world2(tmp_path, oracle_mod):
     for i in range(6):
         r = oracle_mod.OracleOSQP().setup(P=s["P"], q=Q[i], A=s["A"], l=L[i], u=U[i]).solve()
         assert np.array_equal(a[i, :s["n"]], r.x) and a[i, s["n"] + s["m"]] == r.info.iter
+
+
+def test_binary_problem_file_round_trip(product_lib, tmp_path):
+    """osqp_amd_write_problem / osqp_amd_read_problem (C) and osqp_amd.io (numpy) read each
+    other's files; malformed input is rejected with code 3."""
+    from osqp_amd import abi, io
+    pb, _ = load_golden("primal_infeasibility")
+    path = str(tmp_path / "qp.bin")
+    io.save_problem(path, **pb)
+    L = product_lib
+    L.osqp_amd_read_problem.restype = abi.c_int
+    L.osqp_amd_read_problem.argtypes = [C.c_char_p, C.POINTER(C.POINTER(abi.OSQPData))]
+    L.osqp_amd_write_problem.restype = abi.c_int
+    L.osqp_amd_write_problem.argtypes = [C.c_char_p, C.POINTER(abi.OSQPData)]
+    L.osqp_amd_free_problem.restype = None
+    L.osqp_amd_free_problem.argtypes = [C.POINTER(abi.OSQPData)]
+    d = C.POINTER(abi.OSQPData)()
+    assert L.osqp_amd_read_problem(path.encode(), C.byref(d)) == 0
+    assert (d.contents.n, d.contents.m) == (50, 150)
+    path2 = str(tmp_path / "qp2.bin")
+    assert L.osqp_amd_write_problem(path2.encode(), d) == 0
+    L.osqp_amd_free_problem(d)
+    back = io.load_problem(path2)
+    from scipy import sparse
+    assert np.array_equal(back["q"], pb["q"])
+    assert np.array_equal(back["l"], np.clip(pb["l"], -1e30, 1e30))
+    assert (abs(back["A"] - sparse.csc_matrix(pb["A"])).nnz == 0)
+    assert (abs(back["P"] - sparse.triu(pb["P"], format="csc")).nnz == 0)
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"OSQPAMD1" + b"\x00" * 16)
+    assert L.osqp_amd_read_problem(str(bad).encode(), C.byref(d)) == 3
