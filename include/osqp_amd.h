@@ -82,6 +82,7 @@ typedef struct {
   c_float pcg_eps_abs;
   c_int   pcg_max_iter;
   c_int   device;
+  c_int   pcg_adaptive;   /* 1: inexact solves, PCG tolerance tied to the ADMM residuals (not parity-exact; OSQP_AMD_PCG_ADAPTIVE) */
 } osqp_amd_options;
 void  osqp_amd_get_options(osqp_amd_options *opt);
 void  osqp_amd_set_options(const osqp_amd_options *opt);

@@ -17,7 +17,7 @@ __all__ = ["OSQP", "BatchOSQP", "solve_many", "abi", "lib", "build", "engine_opt
 
 class _Options(C.Structure):
     _fields_ = [("pcg_eps_rel", abi.c_float), ("pcg_eps_abs", abi.c_float),
-                ("pcg_max_iter", abi.c_int), ("device", abi.c_int)]
+                ("pcg_max_iter", abi.c_int), ("device", abi.c_int), ("pcg_adaptive", abi.c_int)]
 
 
 class _Stats(C.Structure):

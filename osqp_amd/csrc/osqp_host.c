@@ -54,6 +54,8 @@ static void opt_init(void) {
   if (g_opt_init) return;
   const char *s;
   g_opt.pcg_eps_rel = 1e-10; g_opt.pcg_eps_abs = 1e-15; g_opt.pcg_max_iter = 0; g_opt.device = 0;
+  g_opt.pcg_adaptive = 0;
+  if ((s = getenv("OSQP_AMD_PCG_ADAPTIVE"))) g_opt.pcg_adaptive = atoll(s);
   if ((s = getenv("OSQP_AMD_PCG_EPS_REL")))  g_opt.pcg_eps_rel = atof(s);
   if ((s = getenv("OSQP_AMD_PCG_EPS_ABS")))  g_opt.pcg_eps_abs = atof(s);
   if ((s = getenv("OSQP_AMD_PCG_MAX_ITER"))) g_opt.pcg_max_iter = atoll(s);
@@ -714,6 +716,13 @@ c_int osqp_solve(OSQPWorkspace *w) {
 
   hipeng_params prm;
   fill_params(&prm, st->sigma, st->alpha, w->data->n);
+  /* opt-in inexact mode (not parity-exact): the linear solves are only as accurate as the ADMM
+   * iterate needs -- PCG stops at lambda * sqrt(||r_prim|| * ||r_dual||) (scaled residuals of the
+   * last evaluation), the rule of Schubiger, Banjac, Lygeros (JPDC 144, 2020) cited by the
+   * reference (docs/citing/index.rst:45-59); until the first evaluation a loose relative one */
+  const c_int adaptive_pcg = g_opt.pcg_adaptive;
+  const c_float strict_rel = prm.pcg_eps_rel;
+  if (adaptive_pcg) prm.pcg_eps_rel = 1e-3;
   if (hipeng_set_params(s->eng, &prm)) { exitflag = 1; goto done; }
 
   c_int rho_interval = st->adaptive_rho_interval;
@@ -750,6 +759,12 @@ c_int osqp_solve(OSQPWorkspace *w) {
       if (refresh_info(w, iter, with_obj)) { exitflag = 1; goto done; }
       if (can_print) { print_line(w); w->summary_printed = 1; }
       if (can_check && decide_termination(w, 0)) break;
+    }
+    if (adaptive_pcg && s->sc_iter == iter) {
+      const c_float lam = 0.15;
+      prm.pcg_eps_rel = strict_rel;
+      prm.pcg_eps_abs = lam * sqrt(HMAX(s->sc.pri_res_s, 1e-300) * HMAX(s->sc.dua_res_s, 1e-300));
+      if (hipeng_set_params(s->eng, &prm)) { exitflag = 1; goto done; }
     }
     if (st->adaptive_rho && rho_interval && (iter % rho_interval == 0)) {
       if (!can_check && !can_print && refresh_info(w, iter, with_obj)) { exitflag = 1; goto done; }

@@ -120,3 +120,36 @@ def test_lasso_mid_size_properties(gpu_lib):
     assert s.update(Ax=Ax_new) == 0
     r2 = s.solve()
     assert r2.info.status == "solved" and r2.info.iter <= cold_iters
+
+
+@pytest.fixture
+def inexact_mode():
+    import osqp_amd
+    osqp_amd.set_engine_options(pcg_adaptive=1)
+    yield
+    osqp_amd.set_engine_options(pcg_adaptive=0)
+
+
+def test_inexact_mode_properties(gpu_lib, oracle_mod, inexact_mode):
+    """Opt-in inexact mode (osqp_amd_options.pcg_adaptive): the PCG stop follows the ADMM
+    residuals, so iterates differ from the reference's by design.  What must still hold:
+    status solved, KKT residuals of the returned point within the requested tolerances,
+    objective equal to the exact-mode one to the ADMM tolerance, and fewer PCG iterations."""
+    import osqp_amd
+    from osqp_amd.problems import random_sparse_qp, portfolio_qp
+    eps = 1e-4
+    for pb in (random_sparse_qp(1500, 3000, seed=4), portfolio_qp(8, 25, sector_rows=5, seed=3)):
+        s = osqp_amd.OSQP().setup(**pb, eps_abs=eps, eps_rel=eps)
+        r = s.solve()
+        ro = oracle_mod.OracleOSQP().setup(**pb, eps_abs=eps, eps_rel=eps).solve()
+        assert r.info.status == ro.info.status == "solved"
+        pri, dua, ps, ds = _kkt(pb, r)
+        assert pri <= eps + eps * ps + 1e-9 and dua <= eps + eps * ds + 1e-9
+        assert abs(r.info.obj_val - ro.info.obj_val) <= 10 * eps * max(1.0, abs(ro.info.obj_val))
+        assert r.info.iter <= 2 * ro.info.iter
+        st = s.stats()
+        assert st["pcg_forced"] == 0
+        osqp_amd.set_engine_options(pcg_adaptive=0)
+        s2 = osqp_amd.OSQP().setup(**pb, eps_abs=eps, eps_rel=eps); s2.solve()
+        osqp_amd.set_engine_options(pcg_adaptive=1)
+        assert st["pcg_iters_total"] < s2.stats()["pcg_iters_total"]
