@@ -55,7 +55,7 @@ struct BPattern {          // shared sparsity (device pointers)
 struct BSettings {
   double rho, sigma, alpha, eps_abs, eps_rel, eps_pinf, eps_dinf, rho_tol, adapt_tol;
   int scaling, adaptive_rho, rho_interval, max_iter, check_termination, scaled_termination,
-      warm_start, refine, profile;
+      warm_start, refine, profile, ablate;
 };
 
 struct BIO {               // per-batch arrays (device)
@@ -75,6 +75,7 @@ struct BIO {               // per-batch arrays (device)
   int    *Wt;              // [B][m] constraint class
   int    *flag;            // [B] 1 = K^-1 must be rebuilt (constraint class changed)
   double *info;            // [B][8]: iter, status, obj, pri, dua, rho_updates, rho_estimate, rho
+  const int *order;        // [B] solve phase: workgroup k works on QP order[k] (longest expected first)
 };
 
 // ---------------------------------------------------------------------------
@@ -144,8 +145,8 @@ struct BL {
 #define s_rinv MV(3)
 #define s_z MV(4)
 #define s_y MV(5)
-#define s_zt MV(6)
-#define s_w MV(7)
+#define s_ws MV(6)   /* m-scratch: refinement, certificates */
+#define s_w MV(7)    /* rho z - y, kept current by the z/y update */
 #define s_dy MV(8)
 #define s_E MV(9)
 #define s_tm MV(10)
@@ -172,6 +173,33 @@ __device__ __forceinline__ double p_row_dot(const BL &s, const double *v, int j)
 // ---------------------------------------------------------------------------
 // register-tiled K^-1: thread (tr, tc) of a 16 x 16 grid owns rows tr*T.. and
 // columns tc*T.. of the (padded) NP x NP matrix, NP = 16*T.
+// Sparse dots split over adjacent lanes (the hot loop's rows and columns hold
+// 1..6 entries: the serial chain per row, not the flop count, sets the latency).
+// Lanes of one quad exchange through DPP quad_perm (no LDS traffic).
+__device__ __forceinline__ double quad_xor1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_xor2(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// y_i = sum_j A_ij v_j by the two lanes (l = 0, 1) of a pair; both return the sum
+__device__ __forceinline__ double a_row_dot2(const BL &s, const double *v, int i, int l) {
+  double acc = 0.0;
+  for (int k = s.Rp[i] + l; k < s.Rp[i + 1]; k += 2) acc += s.Av[s.Rk[k]] * v[s.Rj[k]];
+  return acc + quad_xor1(acc);
+}
+// (A' v)_j by the four lanes (l = 0..3) of a quad; all return the sum
+__device__ __forceinline__ double a_col_dot4(const BL &s, const double *v, int j, int l) {
+  double acc = 0.0;
+  for (int k = s.Ap[j] + l; k < s.Ap[j + 1]; k += 4) acc += s.Av[k] * v[s.Ai[k]];
+  acc += quad_xor1(acc);
+  return acc + quad_xor2(acc);
+}
+
 // ---------------------------------------------------------------------------
 template <int TR, int TC, int GC>
 __device__ __forceinline__ void form_K(double (&a)[TR][TC], int n, const BL &s, double sigma) {
@@ -266,9 +294,8 @@ template <int TR, int TC, int GC>
 __device__ __forceinline__ void tile_gemv(const double (&a)[TR][TC], const double *in, double *out,
                                           double *gp) {
   // partial sums of each thread's tile go through LDS (gp: NP rows x (GC+1) doubles,
-  // one padding word per row => conflict-free writes and reads) and are added in
-  // ascending column-block order by the first NP threads: fixed order, no
-  // cross-lane shuffles.
+  // one padding word per row => conflict-free writes and reads) and are added in a
+  // fixed order by four lanes per row.
   constexpr int NP = 16 * TR;
   const int tr = threadIdx.x / GC, tc = threadIdx.x % GC;
   double bj[TC];
@@ -282,11 +309,18 @@ __device__ __forceinline__ void tile_gemv(const double (&a)[TR][TC], const doubl
     gp[(tr * TR + r) * (GC + 1) + tc] = v;
   }
   __syncthreads();
-  if (threadIdx.x < NP) {
+  {
+    // four lanes per row: each adds a quarter of the GC partials in ascending order,
+    // the quarters are combined by a fixed two-step quad exchange
+    const int row = threadIdx.x >> 2, l = threadIdx.x & 3;
     double v = 0.0;
-#pragma unroll 8
-    for (int t = 0; t < GC; ++t) v += gp[threadIdx.x * (GC + 1) + t];
-    out[threadIdx.x] = v;
+    if (row < NP) {
+#pragma unroll
+      for (int t = 0; t < GC / 4; ++t) v += gp[row * (GC + 1) + l * (GC / 4) + t];
+    }
+    v += quad_xor1(v);
+    v += quad_xor2(v);
+    if (row < NP && l == 0) out[row] = v;
   }
   __syncthreads();
 }
@@ -294,13 +328,23 @@ __device__ __forceinline__ void tile_gemv(const double (&a)[TR][TC], const doubl
 // ---------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------
-template <int TR, int TC, int GC>
-__global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSettings st, BIO io, int phase) {
-  constexpr int NP = 16 * TR, NT = 16 * GC, NW = NT / 64;
+// PH = 0: setup phase (scale, classify, build K^-1, store the workspace);
+// PH = 1: solve phase (load the workspace, ADMM loop, store the solution).
+// Phase time stamps / per-phase accumulators exist only in -DOSQP_AMD_BATCH_DEBUG builds
+// (make BATCH_DEBUG=1): they cost ~26 registers and a 2 us s_memrealtime each.
+#ifdef OSQP_AMD_BATCH_DEBUG
+#define DBG(...) __VA_ARGS__
+#else
+#define DBG(...)
+#endif
+template <int TR, int TC, int GC, int PH>
+__global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSettings st, BIO io) {
+  constexpr int NP = 16 * TR, NT = 16 * GC, NW = NT / 64, phase = PH;
   static_assert(GC * TC == NP, "tile shape");
+  static_assert(4 * NP <= NT, "the GEMV reduction and the column dots use four lanes per row/column");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int n = p.n, m = p.m, tid = threadIdx.x;
-  const long long qp = blockIdx.x;
+  const long long qp = (phase == 1 && io.order) ? io.order[blockIdx.x] : (int)blockIdx.x;
   BL s;
   {
     double *w = lds;
@@ -320,16 +364,14 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
     for (int k = tid; k < tot; k += NT) ib[k] = p.packed[k];
   }
   double a[TR][TC];
-  unsigned long long tstamp[8];
-  tstamp[0] = wall_clock64();
-  const unsigned long long cyc0 = clock64();
+  DBG(unsigned long long tstamp[8]; tstamp[0] = wall_clock64(); const unsigned long long cyc0 = clock64();)
 
   // ---- load: raw problem (setup phase) or the per-QP workspace (solve phase) ---
   double cs = 1.0;   // cost scaling c
   for (int j = tid; j < NP; j += NT) {
     s_q[j] = 0.0; s_x[j] = 0.0; s_xt[j] = 0.0; s_dx[j] = 0.0; s_D[j] = 1.0; s_tn[j] = 0.0; s_b[j] = 0.0;
   }
-  for (int i = tid; i < m; i += NT) { s_z[i] = 0.0; s_y[i] = 0.0; s_E[i] = 1.0; s_dy[i] = 0.0; s_zt[i] = 0.0; }
+  for (int i = tid; i < m; i += NT) { s_z[i] = 0.0; s_y[i] = 0.0; s_E[i] = 1.0; s_dy[i] = 0.0; s_ws[i] = 0.0; }
   __syncthreads();
   const long long nv_ = (long long)p.nnzP + p.nnzA;
   if (phase == 0) {
@@ -351,7 +393,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
   }
   __syncthreads();
 
-  tstamp[1] = wall_clock64();
+  DBG(tstamp[1] = wall_clock64();)
   // ---- Ruiz equilibration (scaling.c:44-156), per QP -------------------------
   for (int pass = 0; phase == 0 && pass < st.scaling; ++pass) {
     for (int j = tid; j < n; j += NT) {
@@ -395,7 +437,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
   if (phase == 0) { for (int i = tid; i < m; i += NT) { s_l[i] = s_l[i] * s_E[i]; s_u[i] = s_u[i] * s_E[i]; } }
   __syncthreads();
 
-  tstamp[2] = wall_clock64();
+  DBG(tstamp[2] = wall_clock64();)
   // ---- rho vector (auxil.c:76-98) and warm start -----------------------------
   double rho = phase == 0 ? st.rho : io.rho_io[qp];
   rho = fmin(fmax(rho, 1e-6), 1e6);
@@ -414,7 +456,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
     for (int i = tid; i < m; i += NT) { s_z[i] = io.Zs[qp * m + i]; s_y[i] = io.Ys[qp * m + i]; }
   }
   __syncthreads();
-  tstamp[3] = wall_clock64();
+  DBG(tstamp[3] = wall_clock64();)
   bool kinv_dirty = false;
   // refinement is applied only to QPs whose K^-1 left a relative residual above 1e-10 in the
   // first solve after it was (re)built; the verdict is kept in bit 1 of flag[]
@@ -423,7 +465,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
   double *Wk = io.Wk + qp * (long long)(NP * NP);
   if (phase == 0 || (qflag & 1)) {
     form_K<TR, TC, GC>(a, n, s, st.sigma);
-    tstamp[4] = wall_clock64();
+    DBG(tstamp[4] = wall_clock64();)
     invert_tiles<TR, TC, GC>(a, s, n);
     kinv_dirty = true; check_pending = true;
   } else {
@@ -431,10 +473,10 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
     for (int r = 0; r < TR; ++r)
 #pragma unroll
       for (int c = 0; c < TC; ++c) a[r][c] = Wk[(r * TC + c) * NT + tid];
-    tstamp[4] = wall_clock64();
+    DBG(tstamp[4] = wall_clock64();)
     if (qflag & 4) check_pending = true;
   }
-  tstamp[5] = wall_clock64();
+  DBG(tstamp[5] = wall_clock64();)
   if (phase == 0) {
     // ---- store the workspace and stop: the solve phase starts from here -------
     double *Wv = io.Wv + qp * nv_;
@@ -464,10 +506,17 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
          S_NZ, S_NAX, S_NQ, S_NATY, S_NPX, S_STATUS, S_RHO, S_COUNT_ };
   enum { F_NORMS = 1, F_STATUS = 2, F_APPROX = 4 };
   if (tid == 0) { for (int k = 0; k < S_COUNT_; ++k) sc[k] = 0.0; sc[S_STATUS] = OSQP_UNSOLVED; sc[S_RHO] = rho; }
+  for (int i = tid; i < m; i += NT) s_w[i] = s_rho[i] * s_z[i] - s_y[i];
   __syncthreads();
   int iter = 0, rho_updates = 0, stage = 0;
+#ifdef OSQP_AMD_BATCH_DEBUG
   unsigned long long pacc[5] = {0, 0, 0, 0, 0}, pt0 = 0, pt1 = 0;
 #define PSTAMP(slot) do { if (st.profile) { pt1 = wall_clock64(); pacc[slot] += pt1 - pt0; pt0 = pt1; } } while (0)
+#define ABL(bit) (st.ablate & (bit))
+#else
+#define PSTAMP(slot) do { } while (0)
+#define ABL(bit) 0
+#endif
   bool norms_fresh = false;
 
   while (stage != 3) {
@@ -475,22 +524,26 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
     bool checked = false, adapt_due = false;
     if (stage == 0) {
       ++iter;
-      if (st.profile) pt0 = wall_clock64();
-      // rhs of the reduced system: b = sigma x - q + A'(rho z - y)
-      for (int i = tid; i < m; i += NT) s_w[i] = s_rho[i] * s_z[i] - s_y[i];
-      __syncthreads();
-      for (int j = tid; j < NP; j += NT)
-        s_b[j] = j < n ? (sigma * s_x[j] - s_q[j]) + a_col_dot(s, s_w, j) : 0.0;
-      __syncthreads();
+      DBG(if (st.profile) pt0 = wall_clock64();)
+      // rhs of the reduced system: b = sigma x - q + A'(rho z - y); w = rho z - y is kept
+      // up to date by the z/y update below.  Four lanes per column.
+      if (!ABL(1)) {
+        const int j = tid >> 2, l = tid & 3;
+        if (j < NP) {
+          const double acc = j < n ? a_col_dot4(s, s_w, j, l) : 0.0;
+          if (l == 0) s_b[j] = j < n ? (sigma * s_x[j] - s_q[j]) + acc : 0.0;
+        }
+        __syncthreads();
+      }
       PSTAMP(0);
-      tile_gemv<TR, TC, GC>(a, s_b, s_xt, s.gp);
+      if (!ABL(2)) tile_gemv<TR, TC, GC>(a, s_b, s_xt, s.gp);
       PSTAMP(1);
       if (st.refine && (need_refine || check_pending)) {   // xt += Kinv (b - K xt)
-        for (int i = tid; i < m; i += NT) s_w[i] = s_rho[i] * a_row_dot(s, s_xt, i);
+        for (int i = tid; i < m; i += NT) s_ws[i] = s_rho[i] * a_row_dot(s, s_xt, i);
         __syncthreads();
         double rmax = 0.0, bmax = 0.0;
         for (int j = tid; j < NP; j += NT) {
-          s_tn[j] = j < n ? s_b[j] - (p_row_dot(s, s_xt, j) + sigma * s_xt[j] + a_col_dot(s, s_w, j)) : 0.0;
+          s_tn[j] = j < n ? s_b[j] - (p_row_dot(s, s_xt, j) + sigma * s_xt[j] + a_col_dot(s, s_ws, j)) : 0.0;
           rmax = fmax(rmax, fabs(s_tn[j])); bmax = fmax(bmax, fabs(s_b[j]));
         }
         if (check_pending) {           // decide once per K^-1 whether refinement is needed at all
@@ -504,16 +557,22 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
         __syncthreads();
       }
       PSTAMP(2);
-      // z~ = A x~ ; x, z, y updates (auxil.c:185-225, proj.c:4-14)
-      for (int i = tid; i < m; i += NT) {
-        const double zt = a_row_dot(s, s_xt, i);
-        const double zo = s_z[i], yo = s_y[i];
-        double v = alpha * zt + oma * zo + s_rinv[i] * yo;
-        v = fmax(v, s_l[i]);
-        const double zn = fmin(v, s_u[i]);
-        const double dy = s_rho[i] * (alpha * zt + oma * zo - zn);
-        s_z[i] = zn; s_dy[i] = dy; s_y[i] = yo + dy;
+      // z~ = A x~ ; x, z, y updates (auxil.c:185-225, proj.c:4-14); two lanes per row
+      if (!ABL(4))
+      for (int i = tid >> 1; i < m; i += NT / 2) {
+        const double zt = a_row_dot2(s, s_xt, i, tid & 1);
+        if ((tid & 1) == 0) {
+          const double zo = s_z[i], yo = s_y[i], ri = s_rho[i];
+          double v = alpha * zt + oma * zo + s_rinv[i] * yo;
+          v = fmax(v, s_l[i]);
+          const double zn = fmin(v, s_u[i]);
+          const double dy = ri * (alpha * zt + oma * zo - zn);
+          const double yn = yo + dy;
+          s_z[i] = zn; s_dy[i] = dy; s_y[i] = yn;
+          s_w[i] = ri * zn - yn;
+        }
       }
+      if (!ABL(8))
       for (int j = tid; j < n; j += NT) {
         const double xo = s_x[j];
         const double xn = alpha * s_xt[j] + oma * xo;
@@ -595,7 +654,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
             double dy = s_dy[i];
             if (s_u[i] > BINF) { if (s_l[i] < -BINF) dy = 0.0; else dy = fmin(dy, 0.0); }
             else if (s_l[i] < -BINF) dy = fmax(dy, 0.0);
-            s_w[i] = dy;
+            s_ws[i] = dy;
             nd = fmax(nd, fabs(unscaled ? s_E[i] * dy : dy));
             lhs += s_u[i] * fmax(dy, 0.0) + s_l[i] * fmin(dy, 0.0);
           }
@@ -603,7 +662,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
           if (nd > 1e-30 && lhs < epi * nd) {
             double mx = 0;
             for (int j = tid; j < n; j += NT) {
-              double v = a_col_dot(s, s_w, j);
+              double v = a_col_dot(s, s_ws, j);
               if (unscaled) v = v / s_D[j];
               mx = fmax(mx, fabs(v));
             }
@@ -665,6 +724,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
             const int t = s.ctype[i];
             if (t == 0) { s_rho[i] = rho; s_rinv[i] = 1.0 / rho; }
             else if (t == 1) { s_rho[i] = 1e3 * rho; s_rinv[i] = 1.0 / s_rho[i]; }
+            s_w[i] = s_rho[i] * s_z[i] - s_y[i];
           }
           __syncthreads();
           form_K<TR, TC, GC>(a, n, s, sigma);
@@ -680,7 +740,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
       stage = 3;
     }
   }
-  tstamp[6] = wall_clock64();
+  DBG(tstamp[6] = wall_clock64();)
   const int status = (int)sc[S_STATUS];
   const double pri_res = sc[S_PRI], dua_res = sc[S_DUA], obj = sc[S_OBJ];
   double rho_est;
@@ -709,9 +769,9 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
     for (int i = tid; i < m; i += NT) { io.Yo[qp * m + i] = OSQP_NAN; io.Ys[qp * m + i] = 0.0; io.Zs[qp * m + i] = 0.0; }
     if (status == OSQP_PRIMAL_INFEASIBLE || status == OSQP_PRIMAL_INFEASIBLE_INACCURATE) {
       double mx = 0;
-      for (int i = tid; i < m; i += NT) { s_w[i] = unscaled ? s_w[i] * s_E[i] : s_w[i]; mx = fmax(mx, fabs(s_w[i])); }
+      for (int i = tid; i < m; i += NT) { s_ws[i] = unscaled ? s_ws[i] * s_E[i] : s_ws[i]; mx = fmax(mx, fabs(s_ws[i])); }
       mx = b_max<NW>(mx, s.red);
-      for (int i = tid; i < m; i += NT) io.DYo[qp * m + i] = s_w[i] * (1.0 / mx);
+      for (int i = tid; i < m; i += NT) io.DYo[qp * m + i] = s_ws[i] * (1.0 / mx);
     }
     if (status == OSQP_DUAL_INFEASIBLE || status == OSQP_DUAL_INFEASIBLE_INACCURATE) {
       double mx = 0;
@@ -720,12 +780,12 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
       for (int j = tid; j < n; j += NT) io.DXo[qp * n + j] = s_tn[j] * (1.0 / mx);
     }
   }
-  if (st.profile && tid == 0) {
+  DBG(if (st.profile && tid == 0) {
     tstamp[7] = wall_clock64();
     for (int k = 0; k < 8; ++k) io.DXo[qp * n + k] = (double)(tstamp[k] - tstamp[0]);
     for (int k = 0; k < 4; ++k) io.DXo[qp * n + 8 + k] = (double)pacc[k];
     io.DXo[qp * n + 12] = (double)(clock64() - cyc0);
-  }
+  })
   if (kinv_dirty) {
 #pragma unroll
     for (int r = 0; r < TR; ++r)
@@ -774,6 +834,40 @@ __global__ void __launch_bounds__(256) k_batch_update(int n, int m, BIO io, cons
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+// Dispatch order of the next solve: QPs sorted by the iteration count of the solve
+// that just finished, longest first.  Workgroups are handed to CUs in blockIdx
+// order as CUs free up, so this is longest-processing-time-first list scheduling
+// and the batch no longer ends on a late-started slow QP.  (The order only moves
+// work between CUs; every QP's arithmetic is untouched.)  Counting sort in one
+// workgroup: 1024 buckets over [0, max iterations], buckets walked from the top,
+// ties broken by QP index so the order is reproducible.
+__global__ void __launch_bounds__(1024) k_batch_order(long long B, const double *info, int *order) {
+  __shared__ int hist[1024], base[1024], wmax[16];
+  const int tid = threadIdx.x;
+  int mx = 1;
+  for (long long b = tid; b < B; b += 1024) mx = max(mx, (int)info[b * 8]);
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_down(mx, o, 64));
+  hist[tid] = 0;
+  if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+  __syncthreads();
+  mx = wmax[0];
+  for (int k = 1; k < 16; ++k) mx = max(mx, wmax[k]);
+  const double sc = 1023.0 / (double)mx;
+  for (long long b = tid; b < B; b += 1024) atomicAdd(&hist[1023 - (int)(info[b * 8] * sc)], 1);
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int k = 0; k < 1024; ++k) { base[k] = acc; acc += hist[k]; } }
+  __syncthreads();
+  // bucket tid: its members in index order (a bucket is short unless all counts are equal,
+  // in which case the scan below is a plain copy of the index range)
+  const int cntb = hist[tid];
+  if (cntb) {
+    int pos = base[tid];
+    if (cntb == B) { for (long long b = 0; b < B; ++b) order[b] = (int)b; }
+    else for (long long b = 0; b < B && pos < base[tid] + cntb; ++b)
+      if (1023 - (int)(info[b * 8] * sc) == tid) order[pos++] = (int)b;
+  }
+}
+
 struct osqp_amd_batch {
   int device = 0, tile = 8, threads = 512;
   long long B = 0;
@@ -787,6 +881,8 @@ struct osqp_amd_batch {
   int solves = 0;
   std::vector<double> h_info;
   double *dQ = nullptr, *dL = nullptr, *dU = nullptr;   // staging for updates
+  int *d_order = nullptr;   // dispatch order for the next solve (k_batch_order)
+  int lpt = 1;
 };
 
 static void batch_launch(osqp_amd_batch *b, int phase);
@@ -825,7 +921,11 @@ static void fill_settings(osqp_amd_batch *b, const OSQPSettings *s) {
   const char *e = getenv("OSQP_AMD_BATCH_REFINE");
   t.refine = e ? atoi(e) : 1;
   e = getenv("OSQP_AMD_BATCH_PROFILE");
-  t.profile = e ? atoi(e) : 0;   // phase time stamps (wall_clock64 ticks) written into DX[0..7]
+  t.profile = e ? atoi(e) : 0;
+  e = getenv("OSQP_AMD_BATCH_ABLATE");   // timing experiments only: skip phases of the loop (results are garbage)
+  t.ablate = e ? atoi(e) : 0;
+  e = getenv("OSQP_AMD_BATCH_LPT");
+  b->lpt = e ? atoi(e) : 1;   // phase time stamps (wall_clock64 ticks) written into DX[0..7]
 }
 
 extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const csc *P, const csc *A,
@@ -857,10 +957,7 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
   b->device = (int)device; b->B = batch; b->n = n; b->m = m;
   b->nnzP = (int)P->p[n]; b->nnzA = (int)A->p[n];
   b->tile = n <= 64 ? 4 : 8;
-  {
-    const char *t = getenv("OSQP_AMD_BATCH_THREADS");
-    b->threads = (t && atoi(t) == 256) ? 256 : 512;   // 512 (8x4 tiles) measured faster than 256 (8x8 tiles spill)
-  }
+  b->threads = 512;   // 8x4 (n <= 128) or 4x2 (n <= 64) register tiles; 256-thread variants (8x8 tiles) spill
   if (hipSetDevice(b->device) != hipSuccess || hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
     delete b; return OSQP_LINSYS_SOLVER_LOAD_ERROR;
   }
@@ -919,6 +1016,7 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
   rc |= balloc(b, &io.Xo, B * n); rc |= balloc(b, &io.Yo, B * m);
   rc |= balloc(b, &io.DXo, B * n); rc |= balloc(b, &io.DYo, B * m);
   rc |= balloc(b, &io.rho_io, B); rc |= balloc(b, &io.info, B * 8);
+  { int *ord = nullptr; rc |= balloc(b, &ord, B); b->d_order = ord; }
   {
     const size_t NPs = (size_t)16 * b->tile;
     rc |= balloc(b, &io.Wv, B * ((size_t)b->nnzP + b->nnzA));
@@ -962,15 +1060,15 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
 
 static void batch_launch(osqp_amd_batch *b, int phase) {
   const dim3 g((unsigned)b->B);
-#define BL_(TR, TC, GC) hipLaunchKernelGGL((k_batch_solve<TR, TC, GC>), g, dim3(16 * GC), b->lds_bytes, b->stream, b->pat, b->st, b->io, phase)
-  if (b->tile == 8) { if (b->threads == 512) BL_(8, 4, 32); else BL_(8, 8, 16); }
-  else              { if (b->threads == 512) BL_(4, 2, 32); else BL_(4, 4, 16); }
+#define BL_(TR, TC, GC, PH) hipLaunchKernelGGL((k_batch_solve<TR, TC, GC, PH>), g, dim3(16 * GC), b->lds_bytes, b->stream, b->pat, b->st, b->io)
+  if (b->tile == 8) { if (phase == 0) BL_(8, 4, 32, 0); else BL_(8, 4, 32, 1); }
+  else              { if (phase == 0) BL_(4, 2, 32, 0); else BL_(4, 2, 32, 1); }
 #undef BL_
 }
 static void batch_set_lds(osqp_amd_batch *b) {
-#define SA_(TR, TC, GC) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_solve<TR, TC, GC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes)
-  if (b->tile == 8) { if (b->threads == 512) SA_(8, 4, 32); else SA_(8, 8, 16); }
-  else              { if (b->threads == 512) SA_(4, 2, 32); else SA_(4, 4, 16); }
+#define SA_(TR, TC, GC, PH) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_solve<TR, TC, GC, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes)
+  if (b->tile == 8) { SA_(8, 4, 32, 0); SA_(8, 4, 32, 1); }
+  else              { SA_(4, 2, 32, 0); SA_(4, 2, 32, 1); }
 #undef SA_
 }
 
@@ -1002,7 +1100,9 @@ extern "C" c_int osqp_amd_batch_update(osqp_amd_batch *b, const c_float *Q, cons
 extern "C" c_int osqp_amd_batch_solve(osqp_amd_batch *b) {
   if (!b) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   BCHK(hipSetDevice(b->device));
+  b->io.order = (b->lpt && b->solves > 0) ? b->d_order : nullptr;   // first solve: no history, index order
   batch_launch(b, 1);
+  if (b->lpt) hipLaunchKernelGGL(k_batch_order, dim3(1), dim3(1024), 0, b->stream, b->B, b->io.info, b->d_order);
   BCHK(hipGetLastError());
   BCHK(hipStreamSynchronize(b->stream));
   b->solves++;

@@ -97,6 +97,25 @@ def test_full_batch_1024_properties(gpu_lib):
     assert np.all(dua <= 1e-3 + 1e-3 * np.maximum(np.abs(r.x @ P).max(axis=1), np.abs(r.y @ A).max(axis=1)) + 1e-9)
 
 
+def test_dispatch_order_does_not_change_results(gpu_lib, monkeypatch):
+    """From the second solve on, workgroups take the QPs longest-first (by the previous
+    solve's iteration counts).  Scheduling only: every solve of a sequence must be
+    bit-identical to the same sequence run in index order (OSQP_AMD_BATCH_LPT=0),
+    for a batch size that is not a multiple of anything."""
+    import osqp_amd
+    from osqp_amd.problems import mpc_batch
+    s, Q, L, U = mpc_batch(batch=333)
+    runs = {}
+    for lpt in ("0", "1"):
+        monkeypatch.setenv("OSQP_AMD_BATCH_LPT", lpt)
+        bs = osqp_amd.BatchOSQP().setup(s["P"], s["A"], Q, L, U, warm_start=0)
+        runs[lpt] = [bs.solve() for _ in range(3)]
+    assert len(set(runs["0"][0].iter.tolist())) > 1            # a real spread of iteration counts to sort
+    for a, b in zip(runs["0"], runs["1"]):
+        assert np.array_equal(a.iter, b.iter) and np.array_equal(a.status_val, b.status_val)
+        assert np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y)
+
+
 def test_one_qp_per_stream_matches_sequential(gpu_lib):
     """Several workspaces (each with its own HIP stream) solved concurrently from a
     thread pool give bit-identical results to solving them one after the other."""
