@@ -42,6 +42,7 @@
 #define TB 256            // threads per workgroup (4 wavefronts of 64)
 #define MAX_CHUNK 2048    // products staged in LDS per workgroup (x2 for dual stream)
 #define LONG_ROW 512      // a row with at least this many entries gets a workgroup of its own (no LDS staging)
+#define HUGE_ROW 8192     // A rows this long are sliced over the whole grid in k_cg_A (partials finished by k_huge_reduce)
 #define MAX_PARTS 1024    // upper bound on workgroups that emit dot partials
 #define INF_BOUND 1e26    // OSQP_INFTY * MIN_SCALING
 
@@ -67,6 +68,7 @@ struct __attribute__((aligned(32))) G4 { double r, w, s, m; };
 struct DevMat {
   int nrows, nblk;
   int nstream;           // blocks [0,nstream) are multi-row stream blocks, [nstream,nblk) single long rows
+  int nwave;             // PCG kernels: long rows [nstream,nwave) take one wavefront each, [nwave,nblk) are huge
   const int    *rowptr;
   const int    *col;
   const double *val;
@@ -110,6 +112,7 @@ struct Ctx {             // static pointers / sizes, passed by value
   double *D, *Dinv, *E, *Einv;
   double *part_rz, *part_rr, *part_bb, *part_pkp, *part_s0, *part_s1, *part_s2, *part_gam, *part_del;
   double *scal;          // reduction outputs (see SC_* below)
+  double *part_h;        // huge A rows: [row][workgroup of k_cg_A] partial dots
   double *redout;        // big mode: [rr, gamma, delta, bb] reduced by k_reduce_parts
   int big;               // grids above MAX_PARTS workgroups: partials are reduced by a one-workgroup kernel
   State  *st;
@@ -657,7 +660,7 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
     __syncthreads();
   }
   // long rows: one wavefront each
-  for (int bi = c.A.nstream + blockIdx.x * (TB / 64) + (threadIdx.x >> 6); bi < c.A.nblk; bi += gridDim.x * (TB / 64)) {
+  for (int bi = c.A.nstream + blockIdx.x * (TB / 64) + (threadIdx.x >> 6); bi < c.A.nwave; bi += gridDim.x * (TB / 64)) {
     const RowBlk lb = c.A.blk[bi];
     double acc;
     if (pre) acc = wave_row_dot(c.A, lb.k0, lb.k1, [&](int cc) { return c.ut[cc]; });
@@ -668,6 +671,41 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
     });
     if ((threadIdx.x & 63) == 0) t[lb.r0] = c.rho[lb.r0] * acc;
   }
+  // huge rows (a budget constraint over every variable, ...): every workgroup takes a
+  // strided slice and leaves one partial; k_huge_reduce adds them in a fixed order
+  for (int bi = c.A.nwave; bi < c.A.nblk; ++bi) {
+    const RowBlk hb = c.A.blk[bi];
+    double s0 = 0.0, s1 = 0.0;
+    int k = hb.k0 + blockIdx.x * TB + threadIdx.x;
+    const int stride = gridDim.x * TB;
+    auto xv = [&](int cc) -> double {
+      if (pre) return c.ut[cc];
+      const G4 g = gold[cc];
+      const double sj = first ? g.w : (g.w + beta * g.s);
+      return g.m * (g.r - alpha * sj);
+    };
+    for (; k + stride < hb.k1; k += 2 * stride) {
+      const int c0 = c.A.col[k], c1 = c.A.col[k + stride];
+      const double v0 = c.A.val[k], v1 = c.A.val[k + stride];
+      s0 += v0 * xv(c0); s1 += v1 * xv(c1);
+    }
+    if (k < hb.k1) s0 += c.A.val[k] * xv(c.A.col[k]);
+    const double tot = block_sum(s0 + s1, red);
+    if (threadIdx.x == 0) c.part_h[(size_t)(bi - c.A.nwave) * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
+// t_i = rho_i * (sum of the k_cg_A partials) for the huge rows of A; one workgroup per row.
+__global__ void __launch_bounds__(TB) k_huge_reduce(Ctx c, int flags) {
+  const State *st = c.st;
+  if (!(flags & 4) && (!st->run || st->done)) return;
+  __shared__ double red[16];
+  const int row = c.A.blk[c.A.nwave + blockIdx.x].r0;
+  const double *part = c.part_h + (size_t)blockIdx.x * c.gridA;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < c.gridA; i += TB) s += part[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) c.ut[c.n + row] = c.rho[row] * s;
 }
 
 __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
@@ -1131,7 +1169,7 @@ __global__ void __launch_bounds__(TB) k_fill(double *p, double v, int cnt) {
 // host side
 // ---------------------------------------------------------------------------
 struct HostMat {         // host image of a device CSR matrix
-  int nrows = 0, ncols = 0, nstream = 0;
+  int nrows = 0, ncols = 0, nstream = 0, nwave = 0;
   std::vector<int> rowptr, col, split;
   std::vector<double> val;
   std::vector<RowBlk> blk;
@@ -1179,15 +1217,18 @@ static int dev_alloc(hipeng *e, T **p, size_t count) {
 
 // Greedy row blocks: as many whole rows as fit `chunk` products (at least one
 // row; a single row may exceed MAX_CHUNK and then takes the long-row path).
-static void build_blocks(HostMat &H, int chunk) {
+static void build_blocks(HostMat &H, int chunk, bool huge_ok) {
   // stream blocks first (runs of consecutive short rows, at most `chunk` products),
   // then one block per long row: the PCG kernels give each long row a wavefront
   H.blk.clear();
-  std::vector<RowBlk> longs;
+  std::vector<RowBlk> longs, huges;
   int r = 0;
   while (r < H.nrows) {
     const int k0 = H.rowptr[r];
-    if (H.rowptr[r + 1] - k0 >= LONG_ROW) { longs.push_back({r, r + 1, k0, H.rowptr[r + 1]}); r++; continue; }
+    if (H.rowptr[r + 1] - k0 >= LONG_ROW) {
+      ((huge_ok && H.rowptr[r + 1] - k0 >= HUGE_ROW) ? huges : longs).push_back({r, r + 1, k0, H.rowptr[r + 1]});
+      r++; continue;
+    }
     int r1 = r + 1;
     while (r1 < H.nrows && H.rowptr[r1 + 1] - H.rowptr[r1] < LONG_ROW &&
            H.rowptr[r1 + 1] - k0 <= chunk && (r1 - r) < 8 * TB) r1++;
@@ -1196,6 +1237,8 @@ static void build_blocks(HostMat &H, int chunk) {
   }
   H.nstream = (int)H.blk.size();
   H.blk.insert(H.blk.end(), longs.begin(), longs.end());
+  H.nwave = (int)H.blk.size();
+  H.blk.insert(H.blk.end(), huges.begin(), huges.end());
 }
 
 static int pick_chunk(long long nnz, int nrows) {
@@ -1229,7 +1272,7 @@ static int upload_mat(hipeng *e, HostMat &H) {
 
 static DevMat dev_view(const HostMat &H) {
   DevMat d;
-  d.nrows = H.nrows; d.nblk = (int)H.blk.size(); d.nstream = H.nstream;
+  d.nrows = H.nrows; d.nblk = (int)H.blk.size(); d.nstream = H.nstream; d.nwave = H.nwave;
   d.rowptr = H.d_rowptr; d.col = H.d_col; d.val = H.d_val; d.split = H.d_split; d.blk = H.d_blk;
   return d;
 }
@@ -1252,7 +1295,7 @@ static void build_A(hipeng *e, const csc *A) {
       H.col[dst] = j; H.val[dst] = A->x[k];
       e->A_csc2csr[k] = dst;
     }
-  build_blocks(H, pick_chunk(nnz, m));
+  build_blocks(H, pick_chunk(nnz, m), true);     // k_cg_A slices huge rows over the grid
 }
 
 // Fused row matrix M = [P_full | A'] with the reference's summation order.
@@ -1296,7 +1339,7 @@ static void build_M(hipeng *e, const csc *P, const csc *A) {
       H.col[d] = n + (int)A->i[k]; H.val[d] = A->x[k]; e->A_toM[k] = d;
     }
   }
-  build_blocks(H, pick_chunk(tot, n));
+  build_blocks(H, pick_chunk(tot, n), false);    // rows of M need their full sum inside k_cg_B
 }
 
 static int upload_vec(hipeng *e, double *dst, const c_float *src, size_t cnt) {
@@ -1352,7 +1395,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
     // when most of A sits in long rows, a 32-byte record gather per entry dominates k_cg_A:
     // do the vector update in its own (tiny) launch and gather plain 8-byte u instead
     long long lnnz = 0;
-    for (size_t q = (size_t)e->A.nstream; q < e->A.blk.size(); q++) lnnz += e->A.blk[q].k1 - e->A.blk[q].k0;
+    for (size_t q = (size_t)e->A.nstream; q < (size_t)e->A.nwave; q++) lnnz += e->A.blk[q].k1 - e->A.blk[q].k0;
     e->split = 2 * lnnz >= (long long)e->A.val.size() && !e->A.val.empty();
   }
   if (const char *sp = getenv("OSQP_AMD_SPLIT")) e->split = atoi(sp) != 0;
@@ -1382,6 +1425,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   DA(part_s0, np); DA(part_s1, np); DA(part_s2, np); DA(part_gam, np); DA(part_del, np);
   DA(scal, SC_COUNT * 16);
   DA(redout, 8);
+  DA(part_h, (size_t)std::max(1, c.A.nblk - c.A.nwave) * c.gridA);
   DA(st, 1);
 #undef DA
   {
@@ -1629,6 +1673,8 @@ extern "C" int hipeng_set_z(hipeng *e, const c_float *z) {
 // ---- graphs ---------------------------------------------------------------
 static void launch_cg_A(hipeng *e, int it, int flags) {
   hipLaunchKernelGGL(k_cg_A, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, it, flags);
+  const int nhuge = e->c.A.nblk - e->c.A.nwave;
+  if (nhuge > 0 && !(flags & 16)) hipLaunchKernelGGL(k_huge_reduce, dim3(nhuge), dim3(TB), 0, e->stream, e->c, flags & 4);
 }
 static void launch_cg_B(hipeng *e, int it, int flags) {
   hipLaunchKernelGGL(k_cg_B, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
@@ -1916,13 +1962,16 @@ extern "C" int hipeng_kernel_bytes(hipeng *e, int which, double *bytes) {
   if (!e || !bytes) return HIPENG_ERR_ARG;
   const double n = e->n, m = e->m;
   const double nnzA = (double)e->A.val.size(), nnzM = (double)e->M.val.size();
+  const double nnzPtriu = (double)e->P_toM_up.size();
   // device layout: fp64 values + int32 indices (12 B per stored entry), one
   // int32 row pointer per row, fp64 vectors; gathers counted once per vector
   if (e->variant == 1) {
     // k_cg_A: A stream; u,w,p,s,r,Minv,x read + p,s,r,x,u written (12n); rho read, t written (2m)
     if (which == 0)      *bytes = nnzA * 12 + (m + 1) * 4 + 8 * (12 * n + 2 * m);
-    // k_cg_B: [P|A'] stream; [u|t] and r read, w written
-    else if (which == 1) *bytes = nnzM * 12 + (n + 1) * 4 + 8 * ((n + m) + 2 * n);
+    // k_cg_B: [P|A'] stream; [u|t] and r read, w written.  P is counted as its stored upper
+    // triangle (each stored entry serves both triangles) although the fused row
+    // matrix M holds both, so the figure does not reward the expanded layout.
+    else if (which == 1) *bytes = (nnzA + nnzPtriu) * 12 + (n + 1) * 4 + 8 * ((n + m) + 2 * n);
     else                 *bytes = 0;
     return 0;
   }

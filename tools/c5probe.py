@@ -1,0 +1,22 @@
+"""Config 5 (portfolio, n=50000, 400 dense 125x125 blocks) and config 3 (Lasso) kernel timings."""
+import os, sys, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, osqp_amd
+from osqp_amd.problems import portfolio_qp, lasso_qp
+L = osqp_amd.lib()
+L.hipeng_time_kernel.restype = C.c_int; L.hipeng_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+L.hipeng_kernel_bytes.restype = C.c_int; L.hipeng_kernel_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+which = sys.argv[1:] or ["portfolio", "lasso"]
+for name in which:
+    pb = portfolio_qp() if name == "portfolio" else {k: v for k, v in lasso_qp().items() if k in "PqAlu"}
+    t0 = time.perf_counter()
+    s = osqp_amd.OSQP().setup(**pb, eps_abs=1e-4, eps_rel=1e-4)
+    ts = time.perf_counter() - t0
+    t0 = time.perf_counter(); r = s.solve(); tv = time.perf_counter() - t0
+    st = s.stats()
+    print("%s: setup %.2fs; %s in %d iters, %.3fs -> %.1f it/s; pcg/it %.1f; %.1f us per PCG iteration" % (
+        name, ts, r.info.status, r.info.iter, tv, r.info.iter / tv, st["pcg_iters_total"] / r.info.iter, 1e6 * tv / st["pcg_iters_total"]))
+    for k, nm in enumerate(("k_cg_A", "k_cg_B")):
+        us = C.c_double(); by = C.c_double()
+        L.hipeng_time_kernel(s.engine(), k, 100, C.byref(us)); L.hipeng_kernel_bytes(s.engine(), k, C.byref(by))
+        print("   %s: %.1f us, %.1f MB -> %.0f GB/s" % (nm, us.value, by.value / 1e6, by.value / us.value / 1e3))
