@@ -76,6 +76,17 @@ struct DevMat {
   const RowBlk *blk;
 };
 
+// Dense diagonal blocks of P (portfolio-style block-diagonal covariance): such a block is
+// kept as a plain dense b x b array (8 B per entry, no index) for the PCG operator kernel;
+// everything else of its rows (the A' part) stays in the sparse remainder matrix.
+#define DENSE_MAX 128          // lanes cover the block's columns in two 64-lane halves
+struct DenseBlk { int c0, b, off, pad; };   // first row/column, size, offset into val
+struct DenseP {
+  int nblk;                  // dense blocks (0: feature off)
+  const DenseBlk *blk;
+  const double *val;         // blocks back to back, each row-major (= column-major: symmetric)
+};
+
 // Written by kernels only; read by the host between windows.
 struct State {
   int    run;          // this ADMM iteration is active (written by the first kernel)
@@ -102,6 +113,8 @@ struct Params {          // mutable scalars (host writes, kernels read)
 struct Ctx {             // static pointers / sizes, passed by value
   int n, m;
   DevMat A, M;
+  DevMat Mk;             // what k_cg_B streams: M itself, or its remainder when P has dense blocks
+  DenseP dP;
   int gridA, gridM;      // launch grids (>=1) of row kernels over A / over M
   double *xy, *z, *zt, *va, *vb, *q, *l, *u, *rho, *rhoinv, *minv, *pdiag;
   double *r, *zz, *kp, *pt0, *pt1, *dxy, *dy, *cvec;
@@ -708,6 +721,9 @@ __global__ void __launch_bounds__(TB) k_huge_reduce(Ctx c, int flags) {
   if (threadIdx.x == 0) c.ut[c.n + row] = c.rho[row] * s;
 }
 
+// DENSE: P has dense diagonal blocks (their column walk keeps 64 loads per lane in flight and
+// needs ~190 registers; the plain instantiation stays lean for the sparse stream path).
+template <bool DENSE>
 __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   if (flags & 64) return;                                                            // timing probe: empty kernel
   State *st = c.st;
@@ -715,9 +731,9 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   if (!bench && it > c.prm->k_expect && (!st->run || st->done)) return;
   const int run = st->run, done = st->done;
   const double sigma = c.prm->sigma;
-  const bool has_blk = (int)blockIdx.x < c.M.nstream;
+  const bool has_blk = (int)blockIdx.x < c.Mk.nstream;
   RowBlk b = {0, 0, 0, 0};
-  if (has_blk) b = c.M.blk[blockIdx.x];
+  if (has_blk) b = c.Mk.blk[blockIdx.x];
   const int cnt = b.k1 - b.k0;
   const bool small = has_blk;
   double ev[EPT];
@@ -725,12 +741,12 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   int rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
   int rp0 = 0, rp1 = 0;
   if (small) {
-    if (b.r0 + rg < b.r1) { rp0 = c.M.rowptr[b.r0 + rg]; rp1 = c.M.rowptr[b.r0 + rg + 1]; }
+    if (b.r0 + rg < b.r1) { rp0 = c.Mk.rowptr[b.r0 + rg]; rp1 = c.Mk.rowptr[b.r0 + rg + 1]; }
     int ecol[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int k = threadIdx.x + e * TB;
-      if (k < cnt) { ecol[e] = c.M.col[b.k0 + k]; ev[e] = c.M.val[b.k0 + k]; }
+      if (k < cnt) { ecol[e] = c.Mk.col[b.k0 + k]; ev[e] = c.Mk.val[b.k0 + k]; }
     }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -743,18 +759,18 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   LDS_DECL(1);
   G4 *gc = c.g4 + (size_t)(it & 1) * c.n;
   double pg = 0, pd = 0, prr = 0;
-  for (int bi = blockIdx.x; bi < c.M.nstream; bi += gridDim.x) {
-    if (bi != (int)blockIdx.x) { b = c.M.blk[bi]; RL = lanes_for(b.r1 - b.r0); rg = threadIdx.x / RL; rlane = threadIdx.x % RL; }
+  for (int bi = blockIdx.x; bi < c.Mk.nstream; bi += gridDim.x) {
+    if (bi != (int)blockIdx.x) { b = c.Mk.blk[bi]; RL = lanes_for(b.r1 - b.r0); rg = threadIdx.x / RL; rlane = threadIdx.x % RL; }
     const int cn = b.k1 - b.k0;
     if (bi == (int)blockIdx.x) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) { const int k = threadIdx.x + e * TB; if (k < cn) lprod[k] = ev[e]; }
-    } else stage_products<1>(c.M, b, c.ut, nullptr, lprod, nullptr);
+    } else stage_products<1>(c.Mk, b, c.ut, nullptr, lprod, nullptr);
     __syncthreads();
     for (int j = b.r0 + rg; j < b.r1; j += TB / RL) {
       int a0, a1;
       if (bi == (int)blockIdx.x && j == b.r0 + rg) { a0 = rp0; a1 = rp1; }
-      else { a0 = c.M.rowptr[j]; a1 = c.M.rowptr[j + 1]; }
+      else { a0 = c.Mk.rowptr[j]; a1 = c.Mk.rowptr[j + 1]; }
       const double acc = row_sum_par(lprod, a0 - b.k0, a1 - b.k0, rlane, RL);
       if (rlane == 0) {
         const double uj = c.ut[j], wj = acc + sigma * uj, rj = gc[j].r;
@@ -765,18 +781,83 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
     __syncthreads();
   }
   // long rows: one wavefront each
-  for (int bi = c.M.nstream + blockIdx.x * (TB / 64) + (threadIdx.x >> 6); bi < c.M.nblk; bi += gridDim.x * (TB / 64)) {
-    const RowBlk lb = c.M.blk[bi];
-    const double acc = wave_row_dot(c.M, lb.k0, lb.k1, [&](int cc) { return c.ut[cc]; });
+  for (int bi = c.Mk.nstream + blockIdx.x * (TB / 64) + (threadIdx.x >> 6); bi < c.Mk.nblk; bi += gridDim.x * (TB / 64)) {
+    const RowBlk lb = c.Mk.blk[bi];
+    const double acc = wave_row_dot(c.Mk, lb.k0, lb.k1, [&](int cc) { return c.ut[cc]; });
     if ((threadIdx.x & 63) == 0) {
       const int j = lb.r0;
       const double uj = c.ut[j], wj = acc + sigma * uj, rj = gc[j].r;
       gc[j].w = wj; pg += rj * uj; pd += wj * uj; prr += rj * rj;
     }
   }
+  // dense diagonal blocks of P, one workgroup per block.  P_b is symmetric, so
+  // y_r = sum_j P_b[j][r] u_j: lane r walks DOWN column r while the wavefront reads row j
+  // contiguously (1 KB, fully coalesced); u_j is uniform.  Wavefront w takes the rows
+  // j = w, w+4, ...; the four partial vectors meet in LDS.  No index loads, no gathers.
+  if (DENSE)
+  for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
+    const DenseBlk d = c.dP.blk[db];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const double *dv = c.dP.val + d.off;
+    const bool h0 = lane < d.b, h1 = lane + 64 < d.b;
+    // every load of the block is issued before anything is consumed: <= 32 rows per wavefront
+    double v0[DENSE_MAX / 4], v1[DENSE_MAX / 4];
+#pragma unroll
+    for (int q = 0; q < DENSE_MAX / 4; ++q) {
+      const int j = w + 4 * q;
+      const double *row = dv + (size_t)j * d.b;
+      v0[q] = (j < d.b && h0) ? row[lane] : 0.0;
+      v1[q] = (j < d.b && h1) ? row[lane + 64] : 0.0;
+    }
+    double *ul = lprod + 4 * DENSE_MAX;                 // u of the block, staged for broadcast reads
+    if ((int)threadIdx.x < DENSE_MAX) ul[threadIdx.x] = (int)threadIdx.x < d.b ? c.ut[d.c0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < DENSE_MAX / 4; ++q) {
+      const double u = ul[min(w + 4 * q, DENSE_MAX - 1)];
+      a0 += v0[q] * u; a1 += v1[q] * u;
+    }
+    lprod[w * DENSE_MAX + lane] = a0; lprod[w * DENSE_MAX + 64 + lane] = a1;
+    __syncthreads();
+    if ((int)threadIdx.x < d.b) {
+      const int r = threadIdx.x, jrow = d.c0 + r;
+      double acc = (lprod[r] + lprod[DENSE_MAX + r]) + (lprod[2 * DENSE_MAX + r] + lprod[3 * DENSE_MAX + r]);
+      for (int k = c.Mk.rowptr[jrow]; k < c.Mk.rowptr[jrow + 1]; ++k) acc += c.Mk.val[k] * c.ut[c.Mk.col[k]];   // A' part
+      const double uj = ul[r], wj = acc + sigma * uj, rj = gc[jrow].r;
+      gc[jrow].w = wj; pg += rj * uj; pd += wj * uj; prr += rj * rj;
+    }
+    __syncthreads();
+  }
   if (flags & 32) { if (pg == 12345.678) c.kp[0] = pd + prr; return; }                // timing probe: no block reductions
   block_sum3(pg, pd, prr, red);
   if (threadIdx.x == 0) { c.part_gam[blockIdx.x] = pg; c.part_del[blockIdx.x] = pd; c.part_rr[blockIdx.x] = prr; }
+}
+
+// Slices of A_i . x for the huge rows of A (every workgroup one strided slice, one partial
+// each); the consumer adds the partials in a fixed order.  Launched only when A has huge rows.
+__global__ void __launch_bounds__(TB) k_huge_dot(Ctx c, const double *x, int always) {
+  if (!always && !c.st->run) return;
+  __shared__ double red[16];
+  for (int bi = c.A.nwave; bi < c.A.nblk; ++bi) {
+    const RowBlk hb = c.A.blk[bi];
+    double s0 = 0.0, s1 = 0.0;
+    int k = hb.k0 + blockIdx.x * TB + threadIdx.x;
+    const int stride = gridDim.x * TB;
+    for (; k + stride < hb.k1; k += 2 * stride) {
+      const int c0 = c.A.col[k], c1 = c.A.col[k + stride];
+      s0 += c.A.val[k] * x[c0]; s1 += c.A.val[k + stride] * x[c1];
+    }
+    if (k < hb.k1) s0 += c.A.val[k] * x[c.A.col[k]];
+    const double tot = block_sum(s0 + s1, red);
+    if (threadIdx.x == 0) c.part_h[(size_t)(bi - c.A.nwave) * gridDim.x + blockIdx.x] = tot;
+  }
+}
+__device__ __forceinline__ double huge_row_sum(const Ctx &c, int bi, double *red) {
+  const double *part = c.part_h + (size_t)(bi - c.A.nwave) * c.gridA;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < c.gridA; i += TB) s += part[i];
+  return block_sum(s, red);
 }
 
 // Last kernel of an ADMM iteration: z~ = A x~, then update_x / update_z (+project)
@@ -824,7 +905,7 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
     }
     for (int i = b.r0 + (longrow ? 0 : threadIdx.x); i < b.r1; i += (longrow ? 1 : TB)) {
       double zt;
-      if (longrow) zt = long_row_dot(c.A, b.k0, b.k1, c.va, red);
+      if (longrow) zt = bi >= c.A.nwave ? huge_row_sum(c, bi, red) : long_row_dot(c.A, b.k0, b.k1, c.va, red);
       else zt = row_sum(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0);
       if (!longrow || threadIdx.x == 0) {
         const double rho = c.rho[i], rinv = c.rhoinv[i], yo = y[i], zo = c.z[i];
@@ -913,7 +994,7 @@ __global__ void __launch_bounds__(TB) k_residuals(Ctx c) {
       if (!longrow) { stage_products<1>(c.A, b, x, nullptr, lprod, nullptr); __syncthreads(); }
       for (int i = b.r0 + (longrow ? 0 : threadIdx.x); i < b.r1; i += (longrow ? 1 : TB)) {
         double ax;
-        if (longrow) ax = long_row_dot(c.A, b.k0, b.k1, x, red);
+        if (longrow) ax = bi >= c.A.nwave ? huge_row_sum(c, bi, red) : long_row_dot(c.A, b.k0, b.k1, x, red);
         else ax = row_sum(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0);
         if (!longrow || threadIdx.x == 0) {
           const double zi = c.z[i], pr = ax + (-1.0) * zi;
@@ -1165,6 +1246,14 @@ __global__ void __launch_bounds__(TB) k_fill(double *p, double v, int cnt) {
   for (int i = blockIdx.x * TB + threadIdx.x; i < cnt; i += gridDim.x * TB) p[i] = v;
 }
 
+// dst[k] = src_val[map[k]] (map < 0: structural zero inside a dense block)
+__global__ void __launch_bounds__(TB) k_repack(const double *src, const int *map, double *dst, long long cnt) {
+  for (long long k = (long long)blockIdx.x * TB + threadIdx.x; k < cnt; k += (long long)gridDim.x * TB) {
+    const int q = map[k];
+    dst[k] = q >= 0 ? src[q] : 0.0;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1182,7 +1271,12 @@ struct hipeng {
   int device = 0;
   int n = 0, m = 0;
   hipStream_t stream = nullptr;
-  HostMat A, M;
+  HostMat A, M, Mr;                    // Mr: remainder of M outside P's dense blocks (empty: no dense blocks)
+  std::vector<int> Mr_src, dP_src;     // slot in M of every Mr entry / dense entry (-1: structural zero)
+  std::vector<DenseBlk> dP_blks;
+  int *d_Mr_src = nullptr, *d_dP_src = nullptr;
+  DenseBlk *d_dP_blks = nullptr;
+  double *d_dP_val = nullptr;
   std::vector<int> A_csc2csr;          // CSC slot of A -> CSR slot
   std::vector<int> P_toM_up, P_toM_lo; // triu(P) slot -> slots in M (lo = -1 on the diagonal)
   std::vector<int> A_toM;              // CSC slot of A -> slot in M
@@ -1217,20 +1311,21 @@ static int dev_alloc(hipeng *e, T **p, size_t count) {
 
 // Greedy row blocks: as many whole rows as fit `chunk` products (at least one
 // row; a single row may exceed MAX_CHUNK and then takes the long-row path).
-static void build_blocks(HostMat &H, int chunk, bool huge_ok) {
+static void build_blocks(HostMat &H, int chunk, bool huge_ok, const std::vector<char> *skip = nullptr) {
   // stream blocks first (runs of consecutive short rows, at most `chunk` products),
   // then one block per long row: the PCG kernels give each long row a wavefront
   H.blk.clear();
   std::vector<RowBlk> longs, huges;
   int r = 0;
   while (r < H.nrows) {
+    if (skip && (*skip)[r]) { r++; continue; }     // rows served by another path (dense blocks of P)
     const int k0 = H.rowptr[r];
     if (H.rowptr[r + 1] - k0 >= LONG_ROW) {
       ((huge_ok && H.rowptr[r + 1] - k0 >= HUGE_ROW) ? huges : longs).push_back({r, r + 1, k0, H.rowptr[r + 1]});
       r++; continue;
     }
     int r1 = r + 1;
-    while (r1 < H.nrows && H.rowptr[r1 + 1] - H.rowptr[r1] < LONG_ROW &&
+    while (r1 < H.nrows && !(skip && (*skip)[r1]) && H.rowptr[r1 + 1] - H.rowptr[r1] < LONG_ROW &&
            H.rowptr[r1 + 1] - k0 <= chunk && (r1 - r) < 8 * TB) r1++;
     H.blk.push_back({r, r1, k0, H.rowptr[r1]});
     r = r1;
@@ -1342,6 +1437,67 @@ static void build_M(hipeng *e, const csc *P, const csc *A) {
   build_blocks(H, pick_chunk(tot, n), false);    // rows of M need their full sum inside k_cg_B
 }
 
+// Dense diagonal blocks of P (BASELINE config 5: block-diagonal covariance).  Column j
+// starts a block iff no later column of triu(P) reaches above row j; a block of 32..128
+// rows that is at least half full becomes a dense array for k_cg_B, the rest of M becomes the
+// remainder matrix Mr.  Values of both are gathered from M on the device (k_repack), so
+// every path that changes M (scaling, osqp_update_P/A) only has to repack.
+static void build_dense(hipeng *e, const csc *P) {
+  const int n = e->n;
+  if (const char *v = getenv("OSQP_AMD_DENSE_P")) if (atoi(v) == 0) return;
+  if (n == 0) return;
+  std::vector<int> lo(n), smin(n + 1, n);
+  for (int j = 0; j < n; j++) {
+    lo[j] = j;
+    for (long long k = P->p[j]; k < P->p[j + 1]; k++) lo[j] = std::min(lo[j], (int)P->i[k]);
+  }
+  for (int j = n - 1; j >= 0; j--) smin[j] = std::min(smin[j + 1], lo[j]);
+  std::vector<char> dense(n, 0);
+  const HostMat &M = e->M;
+  long long off = 0;
+  int s0 = 0;
+  for (int j = 1; j <= n; j++) {
+    if (j < n && smin[j] < j) continue;          // column j (or a later one) still reaches into the block
+    const long long b = j - s0, nnz = P->p[j] - P->p[s0];
+    if (b >= 32 && b <= DENSE_MAX && 2 * nnz - b >= (b * b) / 2 && off + b * b < (1ll << 31)) {
+      for (int i = s0; i < j; i++) dense[i] = 1;
+      e->dP_blks.push_back({s0, (int)b, (int)off, 0});
+      off += b * b;
+    }
+    s0 = j;
+  }
+  if (e->dP_blks.empty()) return;
+  e->dP_src.assign((size_t)off, -1);
+  for (const DenseBlk &d : e->dP_blks)
+    for (int i = d.c0; i < d.c0 + d.b; i++)
+      for (int k = M.rowptr[i]; k < M.split[i]; k++)     // P part of the row: all inside the block
+        e->dP_src[(size_t)d.off + (size_t)(i - d.c0) * d.b + (M.col[k] - d.c0)] = k;
+  HostMat &R = e->Mr;
+  R.nrows = n; R.ncols = M.ncols;
+  R.rowptr.assign(n + 1, 0);
+  for (int i = 0; i < n; i++) R.rowptr[i + 1] = R.rowptr[i] + (M.rowptr[i + 1] - (dense[i] ? M.split[i] : M.rowptr[i]));
+  R.col.resize(R.rowptr[n]); R.val.resize(R.rowptr[n]); e->Mr_src.resize(R.rowptr[n]);
+  for (int i = 0; i < n; i++) {
+    int d = R.rowptr[i];
+    for (int k = dense[i] ? M.split[i] : M.rowptr[i]; k < M.rowptr[i + 1]; k++, d++) {
+      R.col[d] = M.col[k]; R.val[d] = M.val[k]; e->Mr_src[d] = k;
+    }
+  }
+  build_blocks(R, pick_chunk(std::max(1, R.rowptr[n]), n), false, &dense);
+}
+
+// refresh the dense rows and the remainder matrix from the values of M (device side)
+static int repack_dense(hipeng *e) {
+  if (e->dP_blks.empty()) return 0;
+  const long long nr = (long long)e->Mr_src.size(), nd = (long long)e->dP_src.size();
+  if (nr) hipLaunchKernelGGL(k_repack, dim3((unsigned)std::min<long long>(4096, (nr + TB - 1) / TB)), dim3(TB), 0, e->stream,
+                             e->M.d_val, e->d_Mr_src, e->Mr.d_val, nr);
+  hipLaunchKernelGGL(k_repack, dim3((unsigned)std::min<long long>(4096, (nd + TB - 1) / TB)), dim3(TB), 0, e->stream,
+                     e->M.d_val, e->d_dP_src, e->d_dP_val, nd);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int upload_vec(hipeng *e, double *dst, const c_float *src, size_t cnt) {
   if (cnt == 0 || !src) return 0;
   HIPCHK(hipMemcpyAsync(dst, src, cnt * sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -1383,6 +1539,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   HIPCHK(hipEventCreate(&e->ev1));
   build_A(e, A);
   build_M(e, P, A);
+  build_dense(e, P);
   auto pick_rl = [](const HostMat &H) {
     int maxrows = 1;
     for (const RowBlk &b : H.blk) maxrows = std::max(maxrows, b.r1 - b.r0);
@@ -1403,6 +1560,19 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   Ctx &c = e->c;
   c.n = n; c.m = m;
   c.A = dev_view(e->A); c.M = dev_view(e->M);
+  c.Mk = c.M; c.dP = DenseP{0, nullptr, nullptr};
+  if (!e->dP_blks.empty()) {
+    if (upload_mat(e, e->Mr)) return HIPENG_ERR_HIP;
+    if (dev_alloc(e, &e->d_Mr_src, e->Mr_src.size()) || dev_alloc(e, &e->d_dP_src, e->dP_src.size()) ||
+        dev_alloc(e, &e->d_dP_blks, e->dP_blks.size()) || dev_alloc(e, &e->d_dP_val, e->dP_src.size())) return HIPENG_ERR_HIP;
+    if (!e->Mr_src.empty())
+      HIPCHK(hipMemcpyAsync(e->d_Mr_src, e->Mr_src.data(), e->Mr_src.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_dP_src, e->dP_src.data(), e->dP_src.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_dP_blks, e->dP_blks.data(), e->dP_blks.size() * sizeof(DenseBlk), hipMemcpyHostToDevice, e->stream));
+    c.Mk = dev_view(e->Mr);
+    c.dP = DenseP{(int)e->dP_blks.size(), e->d_dP_blks, e->d_dP_val};
+    if (repack_dense(e)) return HIPENG_ERR_HIP;
+  }
   {
     const char *v = getenv("OSQP_AMD_PCG_VARIANT");
     e->variant = v ? atoi(v) : 1;          // 1 = Chronopoulos-Gear (2 kernels / iteration), 0 = classic (3)
@@ -1523,6 +1693,7 @@ extern "C" int hipeng_ruiz_scale(hipeng *e, c_int passes, c_float *D, c_float *E
   }
   hipLaunchKernelGGL(k_ruiz_finish, dim3(elem_grid(std::max(n, m))), dim3(TB), 0, e->stream, c);
   HIPCHK(hipGetLastError());
+  if (repack_dense(e)) return HIPENG_ERR_HIP;
   // host mirrors
   double cc = 1.0;
   HIPCHK(hipMemcpyAsync(&cc, c.scal + SCI(SC_DYLHS), sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -1597,6 +1768,7 @@ extern "C" int hipeng_upload_matrices(hipeng *e, const csc *P, const csc *A) {
   if (upload_vec(e, e->M.d_val, e->M.val.data(), e->M.val.size()) ||
       upload_vec(e, e->A.d_val, e->A.val.data(), e->A.val.size()) ||
       upload_vec(e, e->c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
+  if (repack_dense(e)) return HIPENG_ERR_HIP;
   hipLaunchKernelGGL(k_precond, dim3(elem_grid(n)), dim3(TB), 0, e->stream, e->c);
   // z~ = A x~ for the new A so that the PCG warm start stays consistent
   if (e->m > 0) {
@@ -1613,6 +1785,7 @@ extern "C" int hipeng_upload_matrices(hipeng *e, const csc *P, const csc *A) {
 extern "C" int hipeng_matrices_changed(hipeng *e) {
   if (!e) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
+  if (repack_dense(e)) return HIPENG_ERR_HIP;
   hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
   if (e->m > 0) {
     hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, e->c.va, e->c.zt, 0);
@@ -1677,7 +1850,8 @@ static void launch_cg_A(hipeng *e, int it, int flags) {
   if (nhuge > 0 && !(flags & 16)) hipLaunchKernelGGL(k_huge_reduce, dim3(nhuge), dim3(TB), 0, e->stream, e->c, flags & 4);
 }
 static void launch_cg_B(hipeng *e, int it, int flags) {
-  hipLaunchKernelGGL(k_cg_B, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
+  if (e->c.dP.nblk) hipLaunchKernelGGL(k_cg_B<true>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
+  else hipLaunchKernelGGL(k_cg_B<false>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
   if (e->c.big) hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(1024), 0, e->stream, e->c);
 }
 
@@ -1714,6 +1888,7 @@ static int get_graph(hipeng *e, int K, bool cont, hipGraphExec_t *out) {
     // ping-pong buffers / scalars is preserved
     for (int it = 0; it < K; it++) launch_pcg_iter(e, it + 2, it == 0 ? 2 : 0);
   }
+  if (e->c.A.nblk > e->c.A.nwave) hipLaunchKernelGGL(k_huge_dot, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, (const double *)e->c.va, 0);
   hipLaunchKernelGGL(k_admm_finalize, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c);
   HIPCHK(hipStreamEndCapture(e->stream, &g));
   HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
@@ -1749,7 +1924,7 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   const long long start = s.admm_done;
   long long remaining = count;
   const int cap = std::max(2, e->prm.pcg_max_iter);
-  int guard = 0;
+  int guard = 0, call_max = 0;
   while (remaining > 0) {
     hipGraphExec_t ge;
     if (get_graph(e, e->K, false, &ge)) return HIPENG_ERR_HIP;
@@ -1772,6 +1947,11 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
       if (++guard > 100000) { fprintf(stderr, "osqp_amd: PCG continuation did not terminate\n"); return HIPENG_ERR_HIP; }
     }
     remaining = count - (s.admm_done - start);
+    call_max = std::max(call_max, s.iters_max);
+    if (remaining > 0) {     // the next burst is sized from its predecessor alone: restart the device-side maximum
+      const int zero = 0;
+      HIPCHK(hipMemcpyAsync(&e->c.st->iters_max, &zero, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    }
     if (e->trace) fprintf(stderr, "[osqp_amd] window: K=%d burst=%lld done=%lld iters_max=%d last=%d launches=%lld\n", e->K, burst, (long long)(s.admm_done - start), s.iters_max, s.iters_last, (long long)e->stats.graph_launches);
     // track the iteration count: shrink slowly, grow at once
     const int want = s.iters_max + std::max(3, s.iters_max / 6);   // head-room against drift between windows
@@ -1787,7 +1967,7 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   e->stats.admm_done = (c_int)(s.admm_done - start);
   e->stats.pcg_iters_total = (c_int)s.iters_total;
   e->stats.pcg_iters_last = s.iters_last;
-  e->stats.pcg_iters_max = s.iters_max;
+  e->stats.pcg_iters_max = call_max;
   e->stats.pcg_forced = s.forced;
   e->stats.neg_curvature = s.neg_curv_seen;
   return 0;
@@ -1833,6 +2013,7 @@ extern "C" int hipeng_residuals(hipeng *e, hipeng_scalars *out) {
   if (!e || !out) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipMemsetAsync(e->c.scal, 0, SC_COUNT * 16 * sizeof(double), e->stream));
+  if (e->c.A.nblk > e->c.A.nwave) hipLaunchKernelGGL(k_huge_dot, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, (const double *)e->c.xy, 1);
   hipLaunchKernelGGL(k_residuals, dim3(e->c.gridA + e->c.gridM), dim3(TB), 0, e->stream, e->c);
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(TB), 0, e->stream, e->c);
   HIPCHK(hipGetLastError());
@@ -1924,10 +2105,11 @@ extern "C" int hipeng_spmv(hipeng *e, int which, const c_float *x, c_float *y) {
 extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) {
   const int dbg = (which >> 8) & 0xff;
   which &= 0xff;
-  if (!e || !usec || reps <= 0 || which < 0 || which > 4) return HIPENG_ERR_ARG;
+  if (!e || !usec || reps <= 0 || which < 0 || which > 5) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   const Ctx &c = e->c;
   auto one = [&](int it) {
+    if (which == 5) { hipLaunchKernelGGL(k_pcg_init, dim3(c.gridM), dim3(TB), 0, e->stream, c); return; }   // first kernel of an ADMM iteration
     if (e->variant == 1) {
       if (which == 0) launch_cg_A(e, it, 4);
       else if (which == 3) launch_cg_A(e, it, 4 | 16);

@@ -153,3 +153,29 @@ def test_inexact_mode_properties(gpu_lib, oracle_mod, inexact_mode):
         s2 = osqp_amd.OSQP().setup(**pb, eps_abs=eps, eps_rel=eps); s2.solve()
         osqp_amd.set_engine_options(pcg_adaptive=1)
         assert st["pcg_iters_total"] < s2.stats()["pcg_iters_total"]
+
+
+def test_portfolio_dense_blocks_match_oracle(gpu_lib, oracle_mod, pcg_tol):
+    """Blocks of 40 >= 32 take the dense-row path of k_cg_B (plain dense rows + remainder
+    matrix); also osqp_update_P (values repacked on the device) and a second solve."""
+    import osqp_amd
+    from osqp_amd.problems import portfolio_qp
+    txy, tobj = pcg_tol
+    pb = portfolio_qp(6, 40, sector_rows=4, seed=5)
+    kw = dict(eps_abs=1e-5, eps_rel=1e-5)
+    sg = osqp_amd.OSQP().setup(**pb, **kw); so = oracle_mod.OracleOSQP().setup(**pb, **kw)
+    rg, ro = sg.solve(), so.solve()
+    assert rg.info.status == ro.info.status == "solved"
+    assert rg.info.iter == ro.info.iter and rg.info.rho_updates == ro.info.rho_updates
+    assert _rel(rg.x, ro.x) < txy and _rel(rg.y, ro.y) < txy
+    P = sparse.triu(pb["P"]).tocsc(); P.sort_indices()
+    Px_new = P.data * (1.0 + 0.05 * np.cos(np.arange(P.nnz)))     # keeps diagonal dominance of G G'/b + 0.1 I? no: checked below
+    Pn = sparse.csc_matrix((Px_new, P.indices, P.indptr), shape=P.shape)
+    Pf = (Pn + sparse.triu(Pn, 1).T).toarray()
+    if np.linalg.eigvalsh(Pf).min() <= 0:                          # stay convex: shrink the perturbation
+        Px_new = P.data * (1.0 + 0.001 * np.cos(np.arange(P.nnz)))
+    assert sg.update(Px=Px_new) == 0 and so.update(Px=Px_new) == 0
+    rg, ro = sg.solve(), so.solve()
+    assert rg.info.status == ro.info.status == "solved" and rg.info.iter == ro.info.iter
+    assert _rel(rg.x, ro.x) < txy and _rel(rg.y, ro.y) < txy
+    assert abs(rg.info.obj_val - ro.info.obj_val) <= tobj * max(1.0, abs(ro.info.obj_val))

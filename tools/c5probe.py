@@ -10,12 +10,13 @@ which = sys.argv[1:] or ["portfolio", "lasso"]
 for name in which:
     pb = portfolio_qp() if name == "portfolio" else {k: v for k, v in lasso_qp().items() if k in "PqAlu"}
     t0 = time.perf_counter()
-    s = osqp_amd.OSQP().setup(**pb, eps_abs=1e-4, eps_rel=1e-4)
+    s = osqp_amd.OSQP().setup(**pb, eps_abs=1e-4, eps_rel=1e-4, max_iter=int(os.environ.get('PROBE_MAX_ITER', 4000)))
     ts = time.perf_counter() - t0
     t0 = time.perf_counter(); r = s.solve(); tv = time.perf_counter() - t0
     st = s.stats()
     print("%s: setup %.2fs; %s in %d iters, %.3fs -> %.1f it/s; pcg/it %.1f; %.1f us per PCG iteration" % (
         name, ts, r.info.status, r.info.iter, tv, r.info.iter / tv, st["pcg_iters_total"] / r.info.iter, 1e6 * tv / st["pcg_iters_total"]))
+    us = C.c_double(); L.hipeng_time_kernel(s.engine(), 5, 50, C.byref(us)); print("   k_pcg_init: %.1f us" % us.value)
     for k, nm in enumerate(("k_cg_A", "k_cg_B")):
         us = C.c_double(); by = C.c_double()
         L.hipeng_time_kernel(s.engine(), k, 100, C.byref(us)); L.hipeng_kernel_bytes(s.engine(), k, C.byref(by))
