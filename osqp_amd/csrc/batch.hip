@@ -200,6 +200,58 @@ __device__ __forceinline__ double a_col_dot4(const BL &s, const double *v, int j
   return acc + quad_xor2(acc);
 }
 
+// (P v)_j from the full symmetric pattern by the four lanes of a quad; all return the sum
+__device__ __forceinline__ double p_row_dot4(const BL &s, const double *v, int j, int l) {
+  double acc = 0.0;
+  for (int k = s.Fp[j] + l; k < s.Fp[j + 1]; k += 4) acc += s.Pv[s.Fk[k]] * v[s.Fi[k]];
+  acc += quad_xor1(acc);
+  return acc + quad_xor2(acc);
+}
+// Wavefront reductions whose result is uniform: two quad exchanges, two mirror steps inside
+// the 16-lane row (DPP, no LDS), then the four row totals are read out by lane.
+__device__ __forceinline__ double dpp_mirror(double v, bool half) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if (half) { lo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); }
+  else      { lo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); }
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_all_max(double v) {
+  v = fmax(v, quad_xor1(v)); v = fmax(v, quad_xor2(v));
+  v = fmax(v, dpp_mirror(v, true)); v = fmax(v, dpp_mirror(v, false));
+  return fmax(fmax(lane_value(v, 0), lane_value(v, 16)), fmax(lane_value(v, 32), lane_value(v, 48)));
+}
+__device__ __forceinline__ double wave_all_sum(double v) {
+  v += quad_xor1(v); v += quad_xor2(v);
+  v += dpp_mirror(v, true); v += dpp_mirror(v, false);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+// NMAX maxima and NSUM sums over the workgroup with two barriers; the combined values are
+// left in buf[NW*(NMAX+NSUM) ...] (maxima first).  buf: >= (NW+1)*(NMAX+NSUM) doubles of LDS.
+template <int NW, int NMAX, int NSUM>
+__device__ __forceinline__ void b_reduce_many(double (&mx)[NMAX], double (&sm)[NSUM], double *buf) {
+  constexpr int K = NMAX + NSUM;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) { const double r = wave_all_max(mx[k]); if (lane == 0) buf[w * K + k] = r; }
+#pragma unroll
+  for (int k = 0; k < NSUM; ++k) { const double r = wave_all_sum(sm[k]); if (lane == 0) buf[w * K + NMAX + k] = r; }
+  __syncthreads();
+  if ((int)threadIdx.x < K) {
+    const int k = threadIdx.x;
+    double r;
+    if (k < NMAX) { r = buf[k]; for (int q = 1; q < NW; ++q) r = fmax(r, buf[q * K + k]); }
+    else {
+      r = (buf[k] + buf[K + k]) + (buf[2 * K + k] + buf[3 * K + k]);
+      if (NW == 8) r += (buf[4 * K + k] + buf[5 * K + k]) + (buf[6 * K + k] + buf[7 * K + k]);
+    }
+    buf[NW * K + k] = r;
+  }
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------
 template <int TR, int TC, int GC>
 __device__ __forceinline__ void form_K(double (&a)[TR][TC], int n, const BL &s, double sigma) {
@@ -503,7 +555,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
   const double alpha = st.alpha, oma = 1.0 - st.alpha, sigma = st.sigma;
   double *sc = s.red + 13;
   enum { S_PRI, S_DUA, S_OBJ, S_NPRI_S, S_NDUA_S, S_NZ_S, S_NAX_S, S_NQ_S, S_NATY_S, S_NPX_S,
-         S_NZ, S_NAX, S_NQ, S_NATY, S_NPX, S_STATUS, S_RHO, S_COUNT_ };
+         S_NZ, S_NAX, S_NQ, S_NATY, S_NPX, S_STATUS, S_RHO, S_ND, S_LHS, S_NDX, S_QDX, S_COUNT_ };
   enum { F_NORMS = 1, F_STATUS = 2, F_APPROX = 4 };
   if (tid == 0) { for (int k = 0; k < S_COUNT_; ++k) sc[k] = 0.0; sc[S_STATUS] = OSQP_UNSOLVED; sc[S_RHO] = rho; }
   for (int i = tid; i < m; i += NT) s_w[i] = s_rho[i] * s_z[i] - s_y[i];
@@ -590,46 +642,63 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
 
     bool term = false;
     if (flags & F_NORMS) {
-      // ---- update_info: residuals and norms (auxil.c:227-318) ----
-      double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
-      for (int i = tid; i < m; i += NT) {
-        const double ax = a_row_dot(s, s_x, i);
-        const double pr = ax + (-1.0) * s_z[i];
-        const double ei = unscaled ? 1.0 / s_E[i] : 1.0;
-        m0 = fmax(m0, fabs(ei * pr)); m1 = fmax(m1, fabs(pr));
-        m2 = fmax(m2, fabs(ei * s_z[i])); m3 = fmax(m3, fabs(s_z[i]));
-        m4 = fmax(m4, fabs(ei * ax)); m5 = fmax(m5, fabs(ax));
+      // ---- update_info: residuals and norms (auxil.c:227-318), plus the cheap halves of both
+      // infeasibility tests (auxil.c:361-512), in two passes and ONE workgroup reduction ----
+      double mx[16], sm[3];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) mx[k] = 0.0;
+      sm[0] = sm[1] = sm[2] = 0.0;
+      for (int i = tid >> 1; i < m; i += NT / 2) {          // rows: two lanes each
+        const double ax = a_row_dot2(s, s_x, i, tid & 1);
+        if ((tid & 1) == 0) {
+          const double zi = s_z[i], pr = ax + (-1.0) * zi;
+          const double ei = unscaled ? 1.0 / s_E[i] : 1.0;
+          mx[0] = fmax(mx[0], fabs(ei * pr)); mx[1] = fmax(mx[1], fabs(pr));
+          mx[2] = fmax(mx[2], fabs(ei * zi)); mx[3] = fmax(mx[3], fabs(zi));
+          mx[4] = fmax(mx[4], fabs(ei * ax)); mx[5] = fmax(mx[5], fabs(ax));
+          // delta_y projected on the polar of the recession cone (is_primal_infeasible)
+          double dy = s_dy[i];
+          const double li = s_l[i], ui = s_u[i];
+          if (ui > BINF) { if (li < -BINF) dy = 0.0; else dy = fmin(dy, 0.0); }
+          else if (li < -BINF) dy = fmax(dy, 0.0);
+          s_ws[i] = dy;
+          mx[14] = fmax(mx[14], fabs(unscaled ? s_E[i] * dy : dy));
+          sm[1] += ui * fmax(dy, 0.0) + li * fmin(dy, 0.0);
+        }
       }
-      m0 = b_max<NW>(m0, s.red); m1 = b_max<NW>(m1, s.red); m2 = b_max<NW>(m2, s.red);
-      m3 = b_max<NW>(m3, s.red); m4 = b_max<NW>(m4, s.red); m5 = b_max<NW>(m5, s.red);
+      {                                                     // columns: four lanes each
+        const int j = tid >> 2, l = tid & 3;
+        if (j < n) {
+          const double px = p_row_dot4(s, s_x, j, l);
+          const double aty = a_col_dot4(s, s_y, j, l);
+          if (l == 0) {
+            const double qj = s_q[j], xj = s_x[j], dxj = s_dx[j];
+            double dr = qj + px;
+            if (m > 0) dr = dr + aty;
+            const double di = unscaled ? 1.0 / s_D[j] : 1.0;
+            mx[6] = fabs(di * dr); mx[7] = fabs(dr);
+            mx[8] = fabs(di * qj); mx[9] = fabs(qj);
+            mx[10] = fabs(di * aty); mx[11] = fabs(aty);
+            mx[12] = fabs(di * px); mx[13] = fabs(px);
+            sm[0] = xj * (0.5 * px + qj);
+            mx[15] = fabs(unscaled ? s_D[j] * dxj : dxj);      // is_dual_infeasible: |delta_x|, q'delta_x
+            sm[2] = qj * dxj;
+          }
+        }
+      }
+      b_reduce_many<NW, 16, 3>(mx, sm, s.gp);
       if (tid == 0) {
-        sc[S_PRI] = m == 0 ? 0.0 : (unscaled ? m0 : m1);
-        sc[S_NPRI_S] = m1; sc[S_NZ] = unscaled ? m2 : m3; sc[S_NZ_S] = m3;
-        sc[S_NAX] = unscaled ? m4 : m5; sc[S_NAX_S] = m5;
-      }
-      double d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, d6 = 0, d7 = 0, ob = 0;
-      for (int j = tid; j < n; j += NT) {
-        const double px = p_row_dot(s, s_x, j);
-        const double aty = a_col_dot(s, s_y, j);
-        double dr = s_q[j] + px;
-        if (m > 0) dr = dr + aty;
-        const double di = unscaled ? 1.0 / s_D[j] : 1.0;
-        d0 = fmax(d0, fabs(di * dr)); d1 = fmax(d1, fabs(dr));
-        d2 = fmax(d2, fabs(di * s_q[j])); d3 = fmax(d3, fabs(s_q[j]));
-        d4 = fmax(d4, fabs(di * aty)); d5 = fmax(d5, fabs(aty));
-        d6 = fmax(d6, fabs(di * px)); d7 = fmax(d7, fabs(px));
-        ob += s_x[j] * (0.5 * px + s_q[j]);
-      }
-      d0 = b_max<NW>(d0, s.red); d1 = b_max<NW>(d1, s.red); d2 = b_max<NW>(d2, s.red); d3 = b_max<NW>(d3, s.red);
-      d4 = b_max<NW>(d4, s.red); d5 = b_max<NW>(d5, s.red); d6 = b_max<NW>(d6, s.red); d7 = b_max<NW>(d7, s.red);
-      ob = b_sum<NW>(ob, s.red);
-      if (tid == 0) {
+        const double *g = s.gp + NW * 19;                 // combined values
+        sc[S_PRI] = m == 0 ? 0.0 : (unscaled ? g[0] : g[1]);
+        sc[S_NPRI_S] = g[1]; sc[S_NZ] = unscaled ? g[2] : g[3]; sc[S_NZ_S] = g[3];
+        sc[S_NAX] = unscaled ? g[4] : g[5]; sc[S_NAX_S] = g[5];
         const double f = unscaled ? cinv : 1.0;
-        sc[S_DUA] = unscaled ? d0 * cinv : d1; sc[S_NDUA_S] = d1;
-        sc[S_NQ] = (unscaled ? d2 : d3) * f; sc[S_NQ_S] = d3;
-        sc[S_NATY] = (unscaled ? d4 : d5) * f; sc[S_NATY_S] = d5;
-        sc[S_NPX] = (unscaled ? d6 : d7) * f; sc[S_NPX_S] = d7;
-        sc[S_OBJ] = ob * (st.scaling ? cinv : 1.0);
+        sc[S_DUA] = unscaled ? g[6] * cinv : g[7]; sc[S_NDUA_S] = g[7];
+        sc[S_NQ] = (unscaled ? g[8] : g[9]) * f; sc[S_NQ_S] = g[9];
+        sc[S_NATY] = (unscaled ? g[10] : g[11]) * f; sc[S_NATY_S] = g[11];
+        sc[S_NPX] = (unscaled ? g[12] : g[13]) * f; sc[S_NPX_S] = g[13];
+        sc[S_OBJ] = g[16] * (st.scaling ? cinv : 1.0);
+        sc[S_ND] = g[14]; sc[S_LHS] = g[17]; sc[S_NDX] = g[15]; sc[S_QDX] = g[18];
       }
       __syncthreads();
       norms_fresh = true;
@@ -648,47 +717,33 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
         if (m == 0) prim_ok = true;
         else if (pri_res < ea + er * fmax(sc[S_NZ], sc[S_NAX])) prim_ok = true;
         else {
-          // is_primal_infeasible (auxil.c:361-424); projected dy kept in w
-          double nd = 0, lhs = 0;
-          for (int i = tid; i < m; i += NT) {
-            double dy = s_dy[i];
-            if (s_u[i] > BINF) { if (s_l[i] < -BINF) dy = 0.0; else dy = fmin(dy, 0.0); }
-            else if (s_l[i] < -BINF) dy = fmax(dy, 0.0);
-            s_ws[i] = dy;
-            nd = fmax(nd, fabs(unscaled ? s_E[i] * dy : dy));
-            lhs += s_u[i] * fmax(dy, 0.0) + s_l[i] * fmin(dy, 0.0);
-          }
-          nd = b_max<NW>(nd, s.red); lhs = b_sum<NW>(lhs, s.red);
+          // is_primal_infeasible (auxil.c:361-424); the projected delta_y is in ws
+          const double nd = sc[S_ND], lhs = sc[S_LHS];
           if (nd > 1e-30 && lhs < epi * nd) {
-            double mx = 0;
+            double mxv = 0;
             for (int j = tid; j < n; j += NT) {
               double v = a_col_dot(s, s_ws, j);
               if (unscaled) v = v / s_D[j];
-              mx = fmax(mx, fabs(v));
+              mxv = fmax(mxv, fabs(v));
             }
-            mx = b_max<NW>(mx, s.red);
-            pinf = mx < epi * nd;
+            mxv = b_max<NW>(mxv, s.red);
+            pinf = mxv < epi * nd;
           }
         }
         if (dua_res < ea + er * fmax(fmax(sc[S_NQ], sc[S_NATY]), sc[S_NPX])) dual_ok = true;
         else {
           // is_dual_infeasible (auxil.c:426-512)
-          double ndx = 0, qdx = 0;
-          for (int j = tid; j < n; j += NT) {
-            ndx = fmax(ndx, fabs(unscaled ? s_D[j] * s_dx[j] : s_dx[j]));
-            qdx += s_q[j] * s_dx[j];
-          }
-          ndx = b_max<NW>(ndx, s.red); qdx = b_sum<NW>(qdx, s.red);
+          const double ndx = sc[S_NDX], qdx = sc[S_QDX];
           const double csc_ = unscaled ? cs : 1.0;
           if (ndx > 1e-30 && qdx < csc_ * edi * ndx) {
-            double mx = 0;
+            double mxv = 0;
             for (int j = tid; j < n; j += NT) {
               double v = p_row_dot(s, s_dx, j);
               if (unscaled) v = v / s_D[j];
-              mx = fmax(mx, fabs(v));
+              mxv = fmax(mxv, fabs(v));
             }
-            mx = b_max<NW>(mx, s.red);
-            if (mx < csc_ * edi * ndx) {
+            mxv = b_max<NW>(mxv, s.red);
+            if (mxv < csc_ * edi * ndx) {
               double viol = 0;
               for (int i = tid; i < m; i += NT) {
                 double v = a_row_dot(s, s_dx, i);
@@ -711,7 +766,6 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
       }
       __syncthreads();
     }
-
     if (stage == 0) {
       if (checked && term) { stage = 3; continue; }
       if (adapt_due) {     // adapt_rho (auxil.c:13-74)
@@ -785,6 +839,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
     for (int k = 0; k < 8; ++k) io.DXo[qp * n + k] = (double)(tstamp[k] - tstamp[0]);
     for (int k = 0; k < 4; ++k) io.DXo[qp * n + 8 + k] = (double)pacc[k];
     io.DXo[qp * n + 12] = (double)(clock64() - cyc0);
+    io.DXo[qp * n + 13] = (double)tstamp[0]; io.DXo[qp * n + 14] = (double)tstamp[7];
   })
   if (kinv_dirty) {
 #pragma unroll
