@@ -123,7 +123,7 @@ struct BL {
   double *Pv, *Av;          // scaled matrix values (triu P, CSC A)
   double *nv, *mv;          // n-vector block (stride NP), m-vector block (stride m)
   double *rowk, *colk;      // Gauss-Jordan exchange (2 x 2 x NP)
-  double *gp;               // GEMV partial sums (32 x NP)
+  double *gp;               // scratch of the fused reductions (256 doubles)
   double *red;
   int *ctype;
   int NP, m;
@@ -341,39 +341,74 @@ __device__ __forceinline__ void invert_tiles(double (&a)[TR][TC], const BL &s, i
   __syncthreads();
 }
 
+// K^-1 for the per-iteration GEMV lives in a second register layout ("G"): eight adjacent
+// lanes share a group of RG = NP/64 rows, lane q of the eight holds the columns
+// {16k + 2q, 16k + 2q + 1}.  The eight partial sums of a row meet through three DPP exchanges
+// (no LDS round trip, one barrier per GEMV), and for a fixed k the eight lanes read 128
+// contiguous bytes of the input vector.  The Gauss-Jordan tiles (layout "I") are converted
+// once per inversion through the per-QP K^-1 array in HBM, which is stored in G order.
+template <int NP> struct GL { static constexpr int RG = NP / 64, CG = NP / 8; };
+
 // out_i = sum_j Kinv_ij in_j ; in / out are LDS vectors of length >= NP
-template <int TR, int TC, int GC>
-__device__ __forceinline__ void tile_gemv(const double (&a)[TR][TC], const double *in, double *out,
-                                          double *gp) {
-  // partial sums of each thread's tile go through LDS (gp: NP rows x (GC+1) doubles,
-  // one padding word per row => conflict-free writes and reads) and are added in a
-  // fixed order by four lanes per row.
-  constexpr int NP = 16 * TR;
-  const int tr = threadIdx.x / GC, tc = threadIdx.x % GC;
-  double bj[TC];
+template <int NP>
+__device__ __forceinline__ void tile_gemv(const double (&ag)[GL<NP>::RG][GL<NP>::CG], const double *in, double *out) {
+  constexpr int RG = GL<NP>::RG, CG = GL<NP>::CG;
+  const int g = threadIdx.x >> 3, q = threadIdx.x & 7;
+  double acc[RG];
 #pragma unroll
-  for (int c = 0; c < TC; ++c) bj[c] = in[tc * TC + c];
+  for (int r = 0; r < RG; ++r) acc[r] = 0.0;
 #pragma unroll
-  for (int r = 0; r < TR; ++r) {
-    double v = 0.0;
+  for (int k = 0; k < CG / 2; ++k) {
+    const double2 bv = *reinterpret_cast<const double2 *>(in + 16 * k + 2 * q);
 #pragma unroll
-    for (int c = 0; c < TC; ++c) v = __builtin_fma(a[r][c], bj[c], v);
-    gp[(tr * TR + r) * (GC + 1) + tc] = v;
+    for (int r = 0; r < RG; ++r) {
+      acc[r] = __builtin_fma(ag[r][2 * k], bv.x, acc[r]);
+      acc[r] = __builtin_fma(ag[r][2 * k + 1], bv.y, acc[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RG; ++r) {
+    double v = acc[r];
+    v += quad_xor1(v); v += quad_xor2(v); v += dpp_mirror(v, true);
+    if (q == 0) out[g * RG + r] = v;
   }
   __syncthreads();
-  {
-    // four lanes per row: each adds a quarter of the GC partials in ascending order,
-    // the quarters are combined by a fixed two-step quad exchange
-    const int row = threadIdx.x >> 2, l = threadIdx.x & 3;
-    double v = 0.0;
-    if (row < NP) {
+}
+// element (i, j) of K^-1 -> position in the per-QP array (G order, slot-major so that the
+// loads of the solve phase are coalesced)
+template <int NP, int NT>
+__device__ __forceinline__ int g_index(int i, int j) {
+  constexpr int RG = GL<NP>::RG, CG = GL<NP>::CG;
+  const int tg = (i / RG) * 8 + ((j & 15) >> 1);
+  const int sg = (i % RG) * CG + ((j >> 4) << 1) + (j & 1);
+  return sg * NT + tg;
+}
+template <int TR, int TC, int GC>
+__device__ __forceinline__ void store_kinv(const double (&a)[TR][TC], double *Wk) {
+  constexpr int NP = 16 * TR, NT = 16 * GC;
+  const int tr = threadIdx.x / GC, tc = threadIdx.x % GC;
 #pragma unroll
-      for (int t = 0; t < GC / 4; ++t) v += gp[row * (GC + 1) + l * (GC / 4) + t];
-    }
-    v += quad_xor1(v);
-    v += quad_xor2(v);
-    if (row < NP && l == 0) out[row] = v;
-  }
+  for (int r = 0; r < TR; ++r)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) Wk[g_index<NP, NT>(tr * TR + r, tc * TC + c)] = a[r][c];
+}
+// (agent-scope loads: inside the loop the array was just rewritten by other lanes of this workgroup)
+template <int NP, int NT>
+__device__ __forceinline__ void load_kinv(double (&ag)[GL<NP>::RG][GL<NP>::CG], double *Wk) {
+#pragma unroll
+  for (int r = 0; r < GL<NP>::RG; ++r)
+#pragma unroll
+    for (int c = 0; c < GL<NP>::CG; ++c)
+      ag[r][c] = __hip_atomic_load(Wk + (r * GL<NP>::CG + c) * NT + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// form K, invert it in the Gauss-Jordan tile layout and leave it in HBM in GEMV order
+template <int TR, int TC, int GC>
+__device__ __forceinline__ void rebuild_kinv(int n, const BL &s, double sigma, double *Wk) {
+  double a[TR][TC];
+  form_K<TR, TC, GC>(a, n, s, sigma);
+  invert_tiles<TR, TC, GC>(a, s, n);
+  store_kinv<TR, TC, GC>(a, Wk);
+  __threadfence();               // the stores are re-read by other lanes of this workgroup
   __syncthreads();
 }
 
@@ -402,8 +437,9 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
     double *w = lds;
     s.NP = NP; s.m = m;
     s.Pv = w; w += p.nnzP; s.Av = w; w += p.nnzA;
+    w += (p.nnzP + p.nnzA) & 1;          // n-vectors are read 16 bytes at a time by the GEMV
     s.nv = w; w += 7 * NP; s.mv = w; w += 11 * m;
-    s.rowk = w; w += 2 * NP; s.colk = w; w += 2 * NP; s.red = w; w += 64; s.gp = w; w += (GC + 1) * NP;
+    s.rowk = w; w += 2 * NP; s.colk = w; w += 2 * NP; s.red = w; w += 64; s.gp = w; w += 256;
     int *iw = reinterpret_cast<int *>(w);
     s.ctype = iw; iw += m;
     int *ib = iw;
@@ -415,7 +451,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
     const int tot = (int)(iw - ib);
     for (int k = tid; k < tot; k += NT) ib[k] = p.packed[k];
   }
-  double a[TR][TC];
+  double ag[GL<NP>::RG][GL<NP>::CG];     // K^-1 in the GEMV layout
   DBG(unsigned long long tstamp[8]; tstamp[0] = wall_clock64(); const unsigned long long cyc0 = clock64();)
 
   // ---- load: raw problem (setup phase) or the per-QP workspace (solve phase) ---
@@ -509,25 +545,17 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
   }
   __syncthreads();
   DBG(tstamp[3] = wall_clock64();)
-  bool kinv_dirty = false;
   // refinement is applied only to QPs whose K^-1 left a relative residual above 1e-10 in the
   // first solve after it was (re)built; the verdict is kept in bit 1 of flag[]
   const int qflag = phase == 0 ? 1 : io.flag[qp];
   bool need_refine = (qflag & 2) != 0, check_pending = false;
   double *Wk = io.Wk + qp * (long long)(NP * NP);
   if (phase == 0 || (qflag & 1)) {
-    form_K<TR, TC, GC>(a, n, s, st.sigma);
-    DBG(tstamp[4] = wall_clock64();)
-    invert_tiles<TR, TC, GC>(a, s, n);
-    kinv_dirty = true; check_pending = true;
-  } else {
-#pragma unroll
-    for (int r = 0; r < TR; ++r)
-#pragma unroll
-      for (int c = 0; c < TC; ++c) a[r][c] = Wk[(r * TC + c) * NT + tid];
-    DBG(tstamp[4] = wall_clock64();)
-    if (qflag & 4) check_pending = true;
-  }
+    rebuild_kinv<TR, TC, GC>(n, s, st.sigma, Wk);
+    check_pending = true;
+  } else if (qflag & 4) check_pending = true;
+  DBG(tstamp[4] = wall_clock64();)
+  if (phase != 0) load_kinv<NP, NT>(ag, Wk);
   DBG(tstamp[5] = wall_clock64();)
   if (phase == 0) {
     // ---- store the workspace and stop: the solve phase starts from here -------
@@ -539,10 +567,6 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
       io.Wl[qp * m + i] = s_l[i]; io.Wu[qp * m + i] = s_u[i]; io.We[qp * m + i] = s_E[i];
       io.Wt[qp * m + i] = s.ctype[i]; io.Zs[qp * m + i] = 0.0; io.Ys[qp * m + i] = 0.0;
     }
-#pragma unroll
-    for (int r = 0; r < TR; ++r)
-#pragma unroll
-      for (int c = 0; c < TC; ++c) Wk[(r * TC + c) * NT + tid] = a[r][c];
     if (tid == 0) { io.Wc[qp] = cs; io.rho_io[qp] = rho; io.flag[qp] = 4; }   // 4: verdict on refinement still open
     return;
   }
@@ -588,7 +612,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
         __syncthreads();
       }
       PSTAMP(0);
-      if (!ABL(2)) tile_gemv<TR, TC, GC>(a, s_b, s_xt, s.gp);
+      if (!ABL(2)) tile_gemv<NP>(ag, s_b, s_xt);
       PSTAMP(1);
       if (st.refine && (need_refine || check_pending)) {   // xt += Kinv (b - K xt)
         for (int i = tid; i < m; i += NT) s_ws[i] = s_rho[i] * a_row_dot(s, s_xt, i);
@@ -604,7 +628,7 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
           check_pending = false;
         }
         __syncthreads();
-        tile_gemv<TR, TC, GC>(a, s_tn, s_dx, s.gp);   // dx is free until the x update below
+        tile_gemv<NP>(ag, s_tn, s_dx);   // dx is free until the x update below
         for (int j = tid; j < n; j += NT) s_xt[j] += s_dx[j];
         __syncthreads();
       }
@@ -781,9 +805,9 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
             s_w[i] = s_rho[i] * s_z[i] - s_y[i];
           }
           __syncthreads();
-          form_K<TR, TC, GC>(a, n, s, sigma);
-          invert_tiles<TR, TC, GC>(a, s, n);
-          kinv_dirty = true; check_pending = true;
+          rebuild_kinv<TR, TC, GC>(n, s, sigma, Wk);
+          load_kinv<NP, NT>(ag, Wk);
+          check_pending = true;
         }
       }
       if (iter >= st.max_iter) stage = checked ? 2 : 1;
@@ -841,12 +865,6 @@ __global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSetting
     io.DXo[qp * n + 12] = (double)(clock64() - cyc0);
     io.DXo[qp * n + 13] = (double)tstamp[0]; io.DXo[qp * n + 14] = (double)tstamp[7];
   })
-  if (kinv_dirty) {
-#pragma unroll
-    for (int r = 0; r < TR; ++r)
-#pragma unroll
-      for (int c = 0; c < TC; ++c) Wk[(r * TC + c) * NT + tid] = a[r][c];
-  }
   if (tid == 0) {
     io.flag[qp] = check_pending ? 4 : (need_refine ? 2 : 0);
     double *inf = io.info + qp * 8;
@@ -1092,7 +1110,7 @@ extern "C" c_int osqp_amd_batch_setup(osqp_amd_batch **out, c_int batch, const c
   if (rc || hipStreamSynchronize(b->stream) != hipSuccess) { osqp_amd_batch_cleanup(b); return OSQP_LINSYS_SOLVER_INIT_ERROR; }
 
   const int NP = 16 * b->tile;
-  b->lds_bytes = sizeof(double) * ((size_t)b->nnzP + b->nnzA + 7 * NP + 11 * (size_t)m + 4 * NP + 64 + (size_t)(b->threads / 16 + 1) * NP) +
+  b->lds_bytes = sizeof(double) * ((size_t)b->nnzP + b->nnzA + 1 + 7 * NP + 11 * (size_t)m + 4 * NP + 64 + 256) +
                  sizeof(int) * ((size_t)m + 4 + 3 * ((size_t)n + 1) + 2 * (size_t)b->nnzP + 2 * (size_t)Fp[n] +
                                 4 * (size_t)b->nnzA + (size_t)m + 1);
   b->lds_bytes = (b->lds_bytes + 15) & ~(size_t)15;
