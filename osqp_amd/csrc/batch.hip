@@ -424,8 +424,11 @@ __device__ __forceinline__ void rebuild_kinv(int n, const BL &s, double sigma, d
 #else
 #define DBG(...)
 #endif
+#ifndef BATCH_WAVES_PER_SIMD
+#define BATCH_WAVES_PER_SIMD 2   // 4 (two workgroups per CU, <= 128 registers) was measured slower: spills lengthen the slowest QP
+#endif
 template <int TR, int TC, int GC, int PH>
-__global__ void __launch_bounds__(16 * GC, 2) k_batch_solve(BPattern p, BSettings st, BIO io) {
+__global__ void __launch_bounds__(16 * GC, PH == 1 ? BATCH_WAVES_PER_SIMD : 2) k_batch_solve(BPattern p, BSettings st, BIO io) {
   constexpr int NP = 16 * TR, NT = 16 * GC, NW = NT / 64, phase = PH;
   static_assert(GC * TC == NP, "tile shape");
   static_assert(4 * NP <= NT, "the GEMV reduction and the column dots use four lanes per row/column");
