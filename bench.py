@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-n", type=int, default=2000, help="size of the bounded CPU sample (m = 2n)")
     ap.add_argument("--batch", type=int, default=1024, help="MPC batch size for the QPs/s leg (0 = skip)")
+    ap.add_argument("--no-inexact", action="store_true", help="skip the opt-in inexact-mode leg (shorter traces under rocprofv3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     return ap.parse_args()
 
@@ -70,7 +71,7 @@ def kernel_roofline(solver, reps=300):
     # --pmc WRITE_SIZE, separate runs; profiles/r01_*_pmc_and_durations.json), same workload only
     traffic = None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_and_durations.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_and_durations.json")))
         if (solver.n, solver.m) == (10000, 20000):
             k = [v for kk, v in prof["kernels"].items() if kk.startswith(dom["kernel"])][0]
             traffic = round(1024.0 * (k["FETCH_SIZE_KB"]["median"] + k["WRITE_SIZE_KB"]["median"]), 1)
@@ -214,12 +215,14 @@ def main():
         return solver.solve()
 
     for _ in range(a.warmup):
-        step()
+        ru_w = step()
     barrier()
     t0 = time.perf_counter()
     iters = 0
     last = None
+    ru_prev = 0
     for _ in range(a.steps):
+        ru_prev = int(last.info.rho_updates) if last is not None else ru_prev
         last = step()
         iters += last.info.iter
     barrier()
@@ -250,12 +253,12 @@ def main():
                        "eps_abs": a.eps, "eps_rel": a.eps, "adaptive_rho_interval": 100,
                        "pcg_eps_rel": osqp_amd.engine_options()["pcg_eps_rel"],
                        "admm_iters_per_solve": int(last.info.iter), "status": last.info.status,
-                       "rho_updates": int(last.info.rho_updates),
+                       "rho_updates_per_solve": int(last.info.rho_updates) - ru_prev if a.steps > 1 else None,
                        "pcg_iters_per_admm_iter": round(pcg_total / max(1, (a.steps + a.warmup) * last.info.iter), 2),
                        "graph_launches": st["graph_launches"], "host_syncs": st["host_syncs"],
                        "parallelism": "replicas x%d (a single QP does not shard)" % world},
         }
-        if world == 1:
+        if world == 1 and not a.no_inexact:
             # opt-in inexact mode (PCG tolerance tied to the ADMM residuals): NOT parity-exact,
             # reported beside the headline, never as `value`
             osqp_amd.set_engine_options(pcg_adaptive=1)
@@ -268,6 +271,7 @@ def main():
             out["inexact_mode"] = {"value": round(fi / tf, 2), "unit": "ADMM iters/s", "admm_iters_per_solve": int(rf.info.iter),
                                    "status": rf.info.status, "obj_rel_diff_vs_strict": abs(rf.info.obj_val - last.info.obj_val) / abs(last.info.obj_val),
                                    "note": "OSQP_AMD_PCG_ADAPTIVE=1; results agree with the strict mode only to the ADMM tolerance"}
+        if world == 1:
             out["roofline"] = kernel_roofline(solver)
             if not a.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.eps)

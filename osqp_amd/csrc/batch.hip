@@ -914,11 +914,11 @@ __global__ void __launch_bounds__(256) k_batch_update(int n, int m, BIO io, cons
 // that just finished, longest first.  Workgroups are handed to CUs in blockIdx
 // order as CUs free up, so this is longest-processing-time-first list scheduling
 // and the batch no longer ends on a late-started slow QP.  (The order only moves
-// work between CUs; every QP's arithmetic is untouched.)  Counting sort in one
-// workgroup: 1024 buckets over [0, max iterations], buckets walked from the top,
-// ties broken by QP index so the order is reproducible.
+// work between CUs; every QP's arithmetic is untouched, so the order inside a bucket
+// may vary from run to run.)  Counting sort in one workgroup: 1024 buckets over
+// [0, max iterations], histogram, exclusive scan, scatter through bucket cursors.
 __global__ void __launch_bounds__(1024) k_batch_order(long long B, const double *info, int *order) {
-  __shared__ int hist[1024], base[1024], wmax[16];
+  __shared__ int hist[1024], wmax[16];
   const int tid = threadIdx.x;
   int mx = 1;
   for (long long b = tid; b < B; b += 1024) mx = max(mx, (int)info[b * 8]);
@@ -931,17 +931,18 @@ __global__ void __launch_bounds__(1024) k_batch_order(long long B, const double 
   const double sc = 1023.0 / (double)mx;
   for (long long b = tid; b < B; b += 1024) atomicAdd(&hist[1023 - (int)(info[b * 8] * sc)], 1);
   __syncthreads();
-  if (tid == 0) { int acc = 0; for (int k = 0; k < 1024; ++k) { base[k] = acc; acc += hist[k]; } }
+  // exclusive scan of the 1024 bucket counts (bucket 0 = most iterations): wavefront scans + 16 totals
+  const int cnt = hist[tid];
+  int incl = cnt;
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
+  if ((tid & 63) == 63) wmax[tid >> 6] = incl;
   __syncthreads();
-  // bucket tid: its members in index order (a bucket is short unless all counts are equal,
-  // in which case the scan below is a plain copy of the index range)
-  const int cntb = hist[tid];
-  if (cntb) {
-    int pos = base[tid];
-    if (cntb == B) { for (long long b = 0; b < B; ++b) order[b] = (int)b; }
-    else for (long long b = 0; b < B && pos < base[tid] + cntb; ++b)
-      if (1023 - (int)(info[b * 8] * sc) == tid) order[pos++] = (int)b;
-  }
+  int base = incl - cnt;
+  for (int k = 0; k < (tid >> 6); ++k) base += wmax[k];
+  __syncthreads();
+  hist[tid] = base;                         // now the bucket's write cursor
+  __syncthreads();
+  for (long long b = tid; b < B; b += 1024) order[atomicAdd(&hist[1023 - (int)(info[b * 8] * sc)], 1)] = (int)b;
 }
 
 struct osqp_amd_batch {
