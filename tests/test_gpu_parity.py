@@ -378,3 +378,30 @@ def test_non_cvx_golden(gpu_lib):
         osqp_amd.OSQP().setup(**pb, adaptive_rho=0, sigma=1e-6)
     r = osqp_amd.OSQP().setup(**pb, adaptive_rho=0, sigma=float(sol["sigma_new"])).solve()
     assert r.info.status_val == abi.OSQP_NON_CVX and r.info.obj_val == abi.OSQP_NAN
+
+
+def test_plain_c_caller_links_and_matches_oracle(gpu_lib, oracle_mod, tmp_path):
+    """examples/c_caller.c is compiled with gcc against include/osqp_amd.h, linked with
+    libosqp_amd.so and run as its own process: the drop-in boundary exercised from C, the
+    way a program written for the reference would use it (setup, solve, update q/l/u, solve)."""
+    import os, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_caller"
+    subprocess.check_call(["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_caller.c"),
+                           "-L", os.path.join(root, "osqp_amd"), "-losqp_amd", "-lm",
+                           "-Wl,-rpath," + os.path.join(root, "osqp_amd"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("solve")]
+    assert len(lines) == 2
+    from osqp_amd.problems import demo_qp
+    so = oracle_mod.OracleOSQP().setup(**demo_qp(), alpha=1.0)
+    refs = [so.solve()]
+    so.update(q=np.array([2.0, 3.0]), l=np.array([2.0, -1.0, -1.0]), u=np.array([2.0, 2.5, 2.5]))
+    refs.append(so.solve())
+    for line, ro in zip(lines, refs):
+        f = dict(re.findall(r"(\w+)=([^ ]+)", line))
+        assert int(f["rc"]) == 0 and int(f["status"]) == ro.info.status_val and int(f["iter"]) == ro.info.iter
+        assert abs(float(f["obj"]) - ro.info.obj_val) <= 1e-8 * max(1.0, abs(ro.info.obj_val))
+        x = np.array([float(v) for v in f["x"].split(",")]); y = np.array([float(v) for v in f["y"].split(",")])
+        assert _rel(x, ro.x) < 1e-6 and _rel(y, ro.y) < 1e-6
