@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=2000, help="size of the bounded CPU sample (m = 2n)")
     ap.add_argument("--batch", type=int, default=1024, help="MPC batch size for the QPs/s leg (0 = skip)")
     ap.add_argument("--no-inexact", action="store_true", help="skip the opt-in inexact-mode leg (shorter traces under rocprofv3)")
+    ap.add_argument("--cpu-batch-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     return ap.parse_args()
 
@@ -160,6 +161,35 @@ def bench_batch(batch, dist, rank, local_rank, world, coll_dev, steps=10, with_c
                gather_ms=round(gather_ms, 3),
                note="one 512-thread workgroup per QP; cold-started solves (warm_start=0) on the set-up batch "
                     "(scaled data + K^-1 resident in HBM, like the reference's workspace); results left in HBM")
+    if world == 1:
+        # MPC-style sequence: the measured state moved a little -> osqp_amd_batch_update (new q, l, u
+        # from the host, H2D included) -> warm-started solve from the previous solution
+        lo_hi = range(lo, hi)
+        V = []
+        for k in (1, 2):
+            Qk, Lk, Uk = np.zeros_like(Q[lo:hi]), np.zeros_like(L[lo:hi]), np.zeros_like(U[lo:hi])
+            for j, b in enumerate(lo_hi):
+                rng = np.random.default_rng(b)
+                x0 = 0.5 * rng.standard_normal(s["nx"]) + 0.02 * k * np.random.default_rng(10_000 * k + b).standard_normal(s["nx"])
+                Qk[j], Lk[j], Uk[j] = s["vectors"](x0)
+            V.append((Qk, Lk, Uk))
+        bw = osqp_amd.BatchOSQP().setup(s["P"], s["A"], Q[lo:hi], L[lo:hi], U[lo:hi], device=local_rank, warm_start=1)
+        bw.solve(fetch=False)
+        for k in range(2):
+            bw.update(Q=V[k][0], L=V[k][1], U=V[k][2]); bw.solve(fetch=False)
+        torch.cuda.synchronize()
+        t_up = t_so = 0.0
+        for k in range(steps):
+            Qk, Lk, Uk = V[k % 2]
+            t0 = time.perf_counter(); bw.update(Q=Qk, L=Lk, U=Uk); torch.cuda.synchronize(); t1 = time.perf_counter()
+            bw.solve(fetch=False); torch.cuda.synchronize(); t2 = time.perf_counter()
+            t_up += t1 - t0; t_so += t2 - t1
+        rw = bw.results()
+        out["warm_start"] = dict(value=round(batch * steps / (t_up + t_so), 1), unit="QPs/s",
+                                 ms_update=round(1e3 * t_up / steps, 4), ms_solve=round(1e3 * t_so / steps, 4),
+                                 mean_iters=round(float(rw.iter.mean()), 2), solved=int((rw.status_val == 1).sum()),
+                                 note="per step: new q,l,u for every QP from the host (state moved by 2 %), "
+                                      "osqp_amd_batch_update (H2D + rescale on the device), warm-started solve")
     if with_cpu and rank == 0 and world == 1:
         import oracle.oracle as orc
         orc.build()
@@ -174,11 +204,44 @@ def bench_batch(batch, dist, rank, local_rank, world, coll_dev, steps=10, with_c
         dtc = (time.perf_counter() - t0) / (reps * nb)
         out["cpu_baseline"] = dict(value=round(1.0 / dtc, 1), unit="QPs/s", cores=1, kind="port",
                                    sample="first %d QPs of the batch, solve only (setup excluded), %d passes" % (nb, reps))
+        # the same on the host cores this one-GPU job may use (one QP per worker process)
+        import subprocess
+        nw = max(1, min(16, os.cpu_count() or 1))
+        per_w = max(1, nb // nw)
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-batch-worker",
+                                   "%d,%d,%g" % (w * per_w, (w + 1) * per_w, 5.0)], stdout=subprocess.PIPE, text=True)
+                 for w in range(nw)]
+        tot, tmax = 0, 0.0
+        for pr in procs:
+            o = pr.communicate()[0].strip().split()
+            if pr.returncode == 0 and len(o) == 2:
+                tot += int(o[0]); tmax = max(tmax, float(o[1]))
+        if tot:
+            out["cpu_baseline_all_cores"] = dict(value=round(tot / tmax, 1), unit="QPs/s", cores=nw, kind="port",
+                                                 sample="%d worker processes, %d QPs each, solve only, ~5 s" % (nw, per_w))
     return out
+
+
+def cpu_batch_worker(spec):
+    """One CPU worker of the batch baseline: QPs [lo, hi) of the MPC batch, solved round-robin for `secs`."""
+    lo, hi, secs = spec.split(",")
+    lo, hi, secs = int(lo), int(hi), float(secs)
+    import oracle.oracle as orc
+    from osqp_amd.problems import mpc_batch
+    s, Q, L, U = mpc_batch(hi)
+    ws = [orc.OracleOSQP().setup(P=s["P"], q=Q[b], A=s["A"], l=L[b], u=U[b], warm_start=0) for b in range(lo, hi)]
+    t0 = time.perf_counter(); done = 0
+    while time.perf_counter() - t0 < secs:
+        for w in ws:
+            w.solve()
+        done += len(ws)
+    print(done, time.perf_counter() - t0)
 
 
 def main():
     a = parse()
+    if a.cpu_batch_worker:
+        return cpu_batch_worker(a.cpu_batch_worker)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

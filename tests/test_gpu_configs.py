@@ -179,3 +179,28 @@ def test_portfolio_dense_blocks_match_oracle(gpu_lib, oracle_mod, pcg_tol):
     assert rg.info.status == ro.info.status == "solved" and rg.info.iter == ro.info.iter
     assert _rel(rg.x, ro.x) < txy and _rel(rg.y, ro.y) < txy
     assert abs(rg.info.obj_val - ro.info.obj_val) <= tobj * max(1.0, abs(ro.info.obj_val))
+
+
+def test_lasso_full_size_properties(gpu_lib):
+    """Config 3 at BASELINE size (n_feat=5000, m_data=10000, 7.5 M non-zeros, rows of 750
+    entries): KKT residuals of the returned point, then osqp_update_A with perturbed data and a
+    warm-started re-solve that needs fewer iterations (docs/examples/lasso.rst:41-63)."""
+    import osqp_amd
+    from osqp_amd.problems import lasso_qp
+    pb = lasso_qp()
+    data = {k: pb[k] for k in "PqAlu"}
+    eps = 1e-3
+    s = osqp_amd.OSQP().setup(**data, eps_abs=eps, eps_rel=eps)
+    r = s.solve()
+    assert r.info.status == "solved"
+    pri, dua, ps, ds = _kkt(data, r)
+    assert pri <= eps + eps * ps + 1e-9 and dua <= eps + eps * ds + 1e-9
+    assert s.stats()["pcg_forced"] == 0
+    A = sparse.csc_matrix(pb["A"]); A.sort_indices()
+    Ax_new = A.data * (1.0 + 1e-4 * np.random.default_rng(0).standard_normal(A.nnz))
+    assert s.update(Ax=Ax_new) == 0
+    r2 = s.solve()
+    assert r2.info.status == "solved" and r2.info.iter <= r.info.iter
+    data2 = dict(data); data2["A"] = sparse.csc_matrix((Ax_new, A.indices, A.indptr), shape=A.shape)
+    pri, dua, ps, ds = _kkt(data2, r2)
+    assert pri <= eps + eps * ps + 1e-9 and dua <= eps + eps * ds + 1e-9
