@@ -145,10 +145,21 @@ enum {  // slots of Ctx::scal (max slots are bit patterns of non-negative double
 // ---------------------------------------------------------------------------
 // wavefront / workgroup reductions (wave = 64 lanes on gfx950)
 // ---------------------------------------------------------------------------
+// Sum over the 64 lanes, result in every lane.  Four DPP exchanges inside the 16-lane rows
+// (quad xor 1, quad xor 2, half-row mirror, row mirror: no LDS traffic, unlike ds_bpermute
+// shuffles), then the four row totals are read out by lane and added in a fixed order.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v += dpp_move<0xB1>(v); v += dpp_move<0x4E>(v); v += dpp_move<0x141>(v); v += dpp_move<0x140>(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
 // Sum over the workgroup, result broadcast to every thread.  `red` holds >= 5
@@ -254,7 +265,13 @@ __device__ __forceinline__ double row_sum(const double *l, int a, int b) {
 __device__ __forceinline__ double row_sum_par(const double *l, int a, int b, int lane, int L) {
   double s = 0.0;
   for (int k = a + lane; k < b; k += L) s += l[k];
-  for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);   // L is a power of two <= 64
+  // L is a power of two <= 64; the first four butterfly steps stay inside a 16-lane row (DPP)
+  if (L >= 2) s += dpp_move<0xB1>(s);
+  if (L >= 4) s += dpp_move<0x4E>(s);
+  if (L >= 8) s += dpp_move<0x141>(s);
+  if (L >= 16) s += dpp_move<0x140>(s);
+  if (L >= 32) s += __shfl_xor(s, 16, 64);
+  if (L == 64) s += __shfl_xor(s, 32, 64);
   return s;
 }
 // lanes per row for a block: as many as fit one pass over its rows (1..64)
@@ -547,8 +564,9 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   int RL = lanes_for(b.r1 - b.r0);
   int rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
   int rp0 = 0, rp1 = 0;
+  double prho = 0.0;                   // rho of this lane group's first row
   if (small) {
-    if (b.r0 + rg < b.r1) { rp0 = c.A.rowptr[b.r0 + rg]; rp1 = c.A.rowptr[b.r0 + rg + 1]; }
+    if (b.r0 + rg < b.r1) { rp0 = c.A.rowptr[b.r0 + rg]; rp1 = c.A.rowptr[b.r0 + rg + 1]; prho = c.rho[b.r0 + rg]; }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int k = threadIdx.x + e * TB;
@@ -668,7 +686,7 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
       if (bi == (int)blockIdx.x && i == b.r0 + rg) { a0 = rp0; a1 = rp1; }
       else { a0 = c.A.rowptr[i]; a1 = c.A.rowptr[i + 1]; }
       const double acc = row_sum_par(lprod, a0 - b.k0, a1 - b.k0, rlane, RL);
-      if (rlane == 0) t[i] = c.rho[i] * acc;
+      if (rlane == 0) t[i] = ((bi == (int)blockIdx.x && i == b.r0 + rg) ? prho : c.rho[i]) * acc;
     }
     __syncthreads();
   }
@@ -733,15 +751,21 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   const double sigma = c.prm->sigma;
   const bool has_blk = (int)blockIdx.x < c.Mk.nstream;
   RowBlk b = {0, 0, 0, 0};
-  if (has_blk) b = c.Mk.blk[blockIdx.x];
+  if (flags & 128) { b.r0 = blockIdx.x * 32; b.r1 = b.r0 + 32; b.k0 = blockIdx.x * 1000; b.k1 = b.k0 + 1000; }   // timing probe: descriptor known without a load
+  else if (has_blk) b = c.Mk.blk[blockIdx.x];
   const int cnt = b.k1 - b.k0;
   const bool small = has_blk;
   double ev[EPT];
   int RL = lanes_for(b.r1 - b.r0);
   int rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
   int rp0 = 0, rp1 = 0;
+  G4 *gc = c.g4 + (size_t)(it & 1) * c.n;
+  double pu = 0.0, pr = 0.0;           // u_j, r_j of this lane group's first row (off the tail's critical path)
   if (small) {
-    if (b.r0 + rg < b.r1) { rp0 = c.Mk.rowptr[b.r0 + rg]; rp1 = c.Mk.rowptr[b.r0 + rg + 1]; }
+    if (b.r0 + rg < b.r1) {
+      rp0 = c.Mk.rowptr[b.r0 + rg]; rp1 = c.Mk.rowptr[b.r0 + rg + 1];
+      pu = c.ut[b.r0 + rg]; pr = gc[b.r0 + rg].r;
+    }
     int ecol[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -757,7 +781,6 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   if (!bench && (!run || done)) return;
   if (flags & 16) { if (ev[0] == 12345.678 && run == 77) c.kp[0] = ev[1]; return; }   // timing probe: launch + prefetch only
   LDS_DECL(1);
-  G4 *gc = c.g4 + (size_t)(it & 1) * c.n;
   double pg = 0, pd = 0, prr = 0;
   for (int bi = blockIdx.x; bi < c.Mk.nstream; bi += gridDim.x) {
     if (bi != (int)blockIdx.x) { b = c.Mk.blk[bi]; RL = lanes_for(b.r1 - b.r0); rg = threadIdx.x / RL; rlane = threadIdx.x % RL; }
@@ -771,9 +794,12 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
       int a0, a1;
       if (bi == (int)blockIdx.x && j == b.r0 + rg) { a0 = rp0; a1 = rp1; }
       else { a0 = c.Mk.rowptr[j]; a1 = c.Mk.rowptr[j + 1]; }
+      if (flags & 128) { a0 = b.k0 + (j - b.r0) * 31; a1 = a0 + 31; }
       const double acc = row_sum_par(lprod, a0 - b.k0, a1 - b.k0, rlane, RL);
       if (rlane == 0) {
-        const double uj = c.ut[j], wj = acc + sigma * uj, rj = gc[j].r;
+        const bool first = bi == (int)blockIdx.x && j == b.r0 + rg;
+        const double uj = first ? pu : c.ut[j], rj = first ? pr : gc[j].r;
+        const double wj = acc + sigma * uj;
         gc[j].w = wj;
         pg += rj * uj; pd += wj * uj; prr += rj * rj;
       }

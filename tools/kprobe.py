@@ -15,3 +15,4 @@ print("k_cg_B full        %.2f us" % t(1))
 print("k_cg_B no blocksum %.2f us" % t(1 | (32 << 8)))
 print("k_cg_B prefetch    %.2f us" % t(1 | (16 << 8)))
 print("k_cg_B empty       %.2f us" % t(1 | (64 << 8)))
+print("k_cg_B known desc  %.2f us" % t(1 | (128 << 8)))
