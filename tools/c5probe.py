@@ -17,6 +17,8 @@ for name in which:
     print("%s: setup %.2fs; %s in %d iters, %.3fs -> %.1f it/s; pcg/it %.1f; %.1f us per PCG iteration" % (
         name, ts, r.info.status, r.info.iter, tv, r.info.iter / tv, st["pcg_iters_total"] / r.info.iter, 1e6 * tv / st["pcg_iters_total"]))
     us = C.c_double(); L.hipeng_time_kernel(s.engine(), 5, 50, C.byref(us)); print("   k_pcg_init: %.1f us" % us.value)
+    for k, nm in ((3, "k_cg_A update-only (split mode)"), (4, "k_cg_A apply-only (split mode)")):
+        us = C.c_double(); L.hipeng_time_kernel(s.engine(), k, 100, C.byref(us)); print("   %s: %.1f us" % (nm, us.value))
     for k, nm in enumerate(("k_cg_A", "k_cg_B")):
         us = C.c_double(); by = C.c_double()
         L.hipeng_time_kernel(s.engine(), k, 100, C.byref(us)); L.hipeng_kernel_bytes(s.engine(), k, C.byref(by))
