@@ -53,7 +53,7 @@ struct BPattern {          // shared sparsity (device pointers)
 };
 
 struct BSettings {
-  double rho, sigma, alpha, eps_abs, eps_rel, eps_pinf, eps_dinf, rho_tol, adapt_tol;
+  double rho, sigma, alpha, eps_abs, eps_rel, eps_pinf, eps_dinf, rho_tol, adapt_tol, refine_tol;
   int scaling, adaptive_rho, rho_interval, max_iter, check_termination, scaled_termination,
       warm_start, refine, profile, ablate;
 };
@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(16 * GC, PH == 1 ? BATCH_WAVES_PER_SIMD : 2) k
   if (tid == 0) { for (int k = 0; k < S_COUNT_; ++k) sc[k] = 0.0; sc[S_STATUS] = OSQP_UNSOLVED; sc[S_RHO] = rho; }
   for (int i = tid; i < m; i += NT) s_w[i] = s_rho[i] * s_z[i] - s_y[i];
   __syncthreads();
-  int iter = 0, rho_updates = 0, stage = 0;
+  int iter = 0, rho_updates = 0, stage = 0, probe_until = 0;
 #ifdef OSQP_AMD_BATCH_DEBUG
   unsigned long long pacc[5] = {0, 0, 0, 0, 0}, pt0 = 0, pt1 = 0;
 #define PSTAMP(slot) do { if (st.profile) { pt1 = wall_clock64(); pacc[slot] += pt1 - pt0; pt0 = pt1; } } while (0)
@@ -617,7 +617,12 @@ __global__ void __launch_bounds__(16 * GC, PH == 1 ? BATCH_WAVES_PER_SIMD : 2) k
       PSTAMP(0);
       if (!ABL(2)) tile_gemv<NP>(ag, s_b, s_xt);
       PSTAMP(1);
-      if (st.refine && (need_refine || check_pending)) {   // xt += Kinv (b - K xt)
+      // One step of iterative refinement, xt += Kinv (b - K xt), for QPs whose K^-1 needs it.
+      // Whether it does is probed (relative residual of the solve above refine_tol) in the first
+      // four iterations after K^-1 was built; one hit turns refinement on for good (kept per QP
+      // across solves).  refine = 2: always on.
+      const bool probe = !need_refine && (check_pending || iter <= probe_until);
+      if (st.refine && (st.refine == 2 || need_refine || probe)) {
         for (int i = tid; i < m; i += NT) s_ws[i] = s_rho[i] * a_row_dot(s, s_xt, i);
         __syncthreads();
         double rmax = 0.0, bmax = 0.0;
@@ -625,10 +630,10 @@ __global__ void __launch_bounds__(16 * GC, PH == 1 ? BATCH_WAVES_PER_SIMD : 2) k
           s_tn[j] = j < n ? s_b[j] - (p_row_dot(s, s_xt, j) + sigma * s_xt[j] + a_col_dot(s, s_ws, j)) : 0.0;
           rmax = fmax(rmax, fabs(s_tn[j])); bmax = fmax(bmax, fabs(s_b[j]));
         }
-        if (check_pending) {           // decide once per K^-1 whether refinement is needed at all
+        if (probe) {
           rmax = b_max<NW>(rmax, s.red); bmax = b_max<NW>(bmax, s.red);
-          need_refine = rmax > 1e-10 * bmax;
-          check_pending = false;
+          need_refine = rmax > st.refine_tol * bmax;
+          if (check_pending) { check_pending = false; probe_until = iter + 3; }
         }
         __syncthreads();
         tile_gemv<NP>(ag, s_tn, s_dx);   // dx is free until the x update below
@@ -997,6 +1002,8 @@ static void fill_settings(osqp_amd_batch *b, const OSQPSettings *s) {
   t.scaled_termination = (int)s->scaled_termination; t.warm_start = (int)s->warm_start;
   const char *e = getenv("OSQP_AMD_BATCH_REFINE");
   t.refine = e ? atoi(e) : 1;
+  e = getenv("OSQP_AMD_BATCH_REFINE_TOL");
+  t.refine_tol = e ? atof(e) : 1e-12;
   e = getenv("OSQP_AMD_BATCH_PROFILE");
   t.profile = e ? atoi(e) : 0;
   e = getenv("OSQP_AMD_BATCH_ABLATE");   // timing experiments only: skip phases of the loop (results are garbage)
