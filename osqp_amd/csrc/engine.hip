@@ -103,11 +103,13 @@ struct State {
   double rz[2];
   double tol2;
   double gam[2], alp[2];   // Chronopoulos-Gear scalars (ping-pong on parity)
+  int    hist_r;           // ADMM iterations since the PCG start vector history was reset (k_pcg_init counts)
 };
 
 struct Params {          // mutable scalars (host writes, kernels read)
   double sigma, alpha, eps_rel, eps_abs, cinv;
   int    pcg_max_iter, use_cvec, has_scaling, k_expect;   // k_expect: PCG iterations the host expects per solve
+  double ex_theta;         // extrapolation of the PCG start vector (0 = plain warm start)
 };
 
 struct Ctx {             // static pointers / sizes, passed by value
@@ -119,6 +121,7 @@ struct Ctx {             // static pointers / sizes, passed by value
   double *xy, *z, *zt, *va, *vb, *q, *l, *u, *rho, *rhoinv, *minv, *pdiag;
   double *r, *zz, *kp, *pt0, *pt1, *dxy, *dy, *cvec;
   double *init_r, *init_z;        // where k_pcg_init puts r0 and Minv r0 (variant dependent)
+  double *vx, *vold;               // PCG start vector [x~0 | rho z~0] (extrapolated) and the previous [x~ | rho z~]
   double *pdir, *ut;               // Chronopoulos-Gear variant: p, [u|t]
   G4     *g4;                      // ... and {r, w, s, Minv} records, ping-ponged on parity (2n)
   int     init_stride;             // element stride of init_r (4 when it points into g4)
@@ -325,8 +328,10 @@ __device__ __forceinline__ double wave_row_dot(const DevMat &Mx, int ka, int kb,
 
 // First kernel of an ADMM iteration: right-hand side b = sigma x - q + A'(rho z - y)
 // (compute_rhs folded into the reduced system), initial residual r = b - K x~0
-// with the warm start x~0 = previous x~, preconditioned residual and the three
-// start-up dot products.  One dual-stream pass over M.
+// with the warm start x~0 (the previous x~, linearly extrapolated by k_admm_finalize once the
+// iterates move smoothly: ADMM iterates follow a linear recurrence, so 2 x~_k - x~_{k-1} is 2-10x
+// closer to x~_{k+1} than x~_k is), preconditioned residual and the three start-up dot
+// products.  One dual-stream pass over M.
 __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
   State *st = c.st;
   if (st->stalled) { if (blockIdx.x == 0 && threadIdx.x == 0) st->run = 0; return; }
@@ -337,13 +342,13 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
     const RowBlk b = c.M.blk[bi];
     const bool longrow = IS_LONG(b);
     if (!longrow) {
-      stage_products<2>(c.M, b, c.va, c.vb, lprod, lprod + MAX_CHUNK);
+      stage_products<2>(c.M, b, c.vx, c.vb, lprod, lprod + MAX_CHUNK);
       __syncthreads();
     }
     for (int j = b.r0 + (longrow ? 0 : threadIdx.x); j < b.r1; j += (longrow ? 1 : TB)) {
       double sA, sB;
       if (longrow) {
-        sA = long_row_dot(c.M, b.k0, b.k1, c.va, red);
+        sA = long_row_dot(c.M, b.k0, b.k1, c.vx, red);
         sB = long_row_dot(c.M, b.k0, b.k1, c.vb, red);
       } else {
         const int a0 = c.M.rowptr[j] - b.k0, a1 = c.M.rowptr[j + 1] - b.k0;
@@ -353,7 +358,7 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
       if (!longrow || threadIdx.x == 0) {
         const double base = prm.use_cvec ? c.cvec[j] : (prm.sigma * c.xy[j] - c.q[j]);
         const double bj = base + sB;
-        const double rj = bj - prm.sigma * c.va[j] - sA;
+        const double rj = bj - prm.sigma * c.vx[j] - sA;
         const double zj = c.minv[j] * rj;
         c.init_r[(size_t)j * c.init_stride] = rj;
         c.init_z[j] = zj;
@@ -367,6 +372,7 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
     c.part_rz[blockIdx.x] = prz; c.part_rr[blockIdx.x] = prr; c.part_bb[blockIdx.x] = pbb;
     if (blockIdx.x == 0) {
       st->run = 1; st->done = 0; st->neg_curv = 0; st->iters[0] = 0; st->iters[1] = 0;
+      if (st->hist_r < (1 << 20)) st->hist_r += 1;
     }
   }
 }
@@ -595,7 +601,7 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   double o_u = 0, o_w = 0, o_p = 0, o_s = 0, o_r = 0, o_x = 0, o_m = 0;
   if (!pre && j0 < c.n) {
     const G4 g = gold[j0];
-    o_u = c.ut[j0]; o_w = g.w; o_p = c.pdir[j0]; o_s = g.s; o_r = g.r; o_x = c.va[j0]; o_m = g.m;
+    o_u = c.ut[j0]; o_w = g.w; o_p = c.pdir[j0]; o_s = g.s; o_r = g.r; o_x = gam_old == 0.0 ? c.vx[j0] : c.va[j0]; o_m = g.m;
   }
   if (cont) {
     if (blockIdx.x == 0 && threadIdx.x == 0) st->run = stalled;
@@ -636,7 +642,7 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
     for (int j = j0; j < c.n; j += gridDim.x * TB) {
       double uj, wj, po, so, ro, xo, mi;
       if (j == j0) { uj = o_u; wj = o_w; po = o_p; so = o_s; ro = o_r; xo = o_x; mi = o_m; }
-      else { const G4 g = gold[j]; uj = c.ut[j]; wj = g.w; po = c.pdir[j]; so = g.s; ro = g.r; xo = c.va[j]; mi = g.m; }
+      else { const G4 g = gold[j]; uj = c.ut[j]; wj = g.w; po = c.pdir[j]; so = g.s; ro = g.r; xo = first ? c.vx[j] : c.va[j]; mi = g.m; }
       const double pj = first ? uj : (uj + beta * po);
       const double sj = first ? wj : (wj + beta * so);
       const double rj = ro - alpha * sj;
@@ -915,12 +921,19 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
     if (st->neg_curv) st->neg_curv_seen += 1;
   }
   const double alpha = prm.alpha, oma = 1.0 - prm.alpha;
+  // start vector of the next PCG solve: [x~ | rho z~] + theta * (change since the previous ADMM
+  // iteration).  No extrapolation in the first iterations after a reset (the iterates still jump),
+  // half a step for a while, then the full linear step.  hist_r is advanced by k_pcg_init only.
+  const int hist = st->hist_r;
+  const double th = (hist < 5 ? 0.0 : (hist < 12 ? 0.5 : 1.0)) * prm.ex_theta;
+  const bool ex = c.vx != c.va;
   double *x = c.xy, *y = c.xy + c.n;
   for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
-    const double xo = x[j];
-    const double xn = alpha * c.va[j] + oma * xo;
+    const double xo = x[j], xt = c.va[j];
+    const double xn = alpha * xt + oma * xo;
     c.dxy[j] = xn - xo;
     x[j] = xn;
+    if (ex) { c.vx[j] = xt + th * (xt - c.vold[j]); c.vold[j] = xt; }
   }
   for (int bi = blockIdx.x; bi < c.A.nblk; bi += gridDim.x) {
     const RowBlk b = c.A.blk[bi];
@@ -941,7 +954,9 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
         const double dy = rho * (alpha * zt + oma * zo - zn);
         const double yn = yo + dy;
         c.z[i] = zn; y[i] = yn; c.dy[i] = dy; c.zt[i] = zt;
-        c.va[c.n + i] = rho * zt;
+        const double rz = rho * zt;
+        c.va[c.n + i] = rz;
+        if (ex) { c.vx[c.n + i] = rz + th * (rz - c.vold[c.n + i]); c.vold[c.n + i] = rz; }
         c.vb[c.n + i] = rho * zn - yn;
       }
     }
@@ -1317,6 +1332,8 @@ struct hipeng {
   bool split = false;     // large A: vector update and operator apply as two launches (plain 8-byte gathers)
   int rlA = 8, rlM = 8;   // lanes per row segment in the PCG kernels
   bool calibrated = false;
+  double ex_theta0 = 1.0;    // OSQP_AMD_EXTRAP (0 disables the extrapolated PCG start)
+  bool start_dirty = true;   // [x~ | rho z~] was rewritten from outside the loop: PCG start history is void
   int warm_windows = 0;   // windows since the last (re)calibration: bursts grow 1, 4, 8, then up to 64
   bool trace = false;
   hipeng_stats stats{};
@@ -1524,6 +1541,15 @@ static int repack_dense(hipeng *e) {
   return 0;
 }
 
+// The PCG start vector history is void (cold/warm start from the host, new rho, new matrices):
+// start from [x~ | rho z~] as it stands and extrapolate again once a few iterations are on record.
+static int reset_start(hipeng *e) {
+  if (e->c.vx != e->c.va)
+    HIPCHK(hipMemcpyAsync(e->c.vx, e->c.va, (size_t)std::max(1, e->n + e->m) * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(hipMemsetAsync(&e->c.st->hist_r, 0, sizeof(int), e->stream));
+  return 0;
+}
+
 static int upload_vec(hipeng *e, double *dst, const c_float *src, size_t cnt) {
   if (cnt == 0 || !src) return 0;
   HIPCHK(hipMemcpyAsync(dst, src, cnt * sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -1615,6 +1641,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   DA(r, n); DA(zz, n); DA(kp, n); DA(pt0, n + m); DA(pt1, n + m);
   DA(dxy, n + m); DA(dy, m); DA(cvec, n);
   DA(pdir, n); DA(ut, n + m); DA(g4, 2 * n);
+  DA(vx, n + m); DA(vold, n + m);
   DA(D, n); DA(Dinv, n); DA(E, m); DA(Einv, m);
   const int np = std::max(std::max(c.gridM, c.gridA), 2048);   // also scratch for the scaling kernels
   DA(part_rz, np); DA(part_rr, np); DA(part_bb, np); DA(part_pkp, np);
@@ -1634,6 +1661,11 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   e->prm.eps_rel = prm->pcg_eps_rel; e->prm.eps_abs = prm->pcg_eps_abs;
   e->prm.pcg_max_iter = (int)prm->pcg_max_iter; e->prm.cinv = 1.0;
   e->prm.use_cvec = 0; e->prm.has_scaling = 0; e->prm.k_expect = 1 << 30;
+  e->prm.ex_theta = 1.0;
+  if (const char *x = getenv("OSQP_AMD_EXTRAP")) e->prm.ex_theta = atof(x);
+  if (e->variant != 1 || e->prm.ex_theta == 0.0) { e->prm.ex_theta = 0.0; c.vx = c.va; }   // classic variant: plain warm start
+  e->ex_theta0 = e->prm.ex_theta;
+  if (prm->pcg_eps_rel < 1e-10) e->prm.ex_theta = 0.0;
   if (push_params(e)) return HIPENG_ERR_HIP;
   if (upload_vec(e, c.q, q, n) || upload_vec(e, c.l, l, m) || upload_vec(e, c.u, u, m) ||
       upload_vec(e, c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
@@ -1670,6 +1702,11 @@ extern "C" int hipeng_set_params(hipeng *e, const hipeng_params *prm) {
   e->prm.sigma = prm->sigma; e->prm.alpha = prm->alpha;
   e->prm.eps_rel = prm->pcg_eps_rel; e->prm.eps_abs = prm->pcg_eps_abs;
   e->prm.pcg_max_iter = (int)prm->pcg_max_iter;
+  // Extrapolated start vectors pay while PCG does real work.  When the caller asks for more
+  // than the default accuracy (tight eps_abs/eps_rel tighten pcg_eps_rel, see osqp_solve) every
+  // digit of the solve counts and the residual-based stop from a closer start leaves a
+  // slightly larger error: plain warm start there.
+  e->prm.ex_theta = prm->pcg_eps_rel >= 1e-10 ? e->ex_theta0 : 0.0;
   if (push_params(e)) return HIPENG_ERR_HIP;
   if (sigma_changed) hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
   return 0;
@@ -1764,7 +1801,7 @@ extern "C" int hipeng_upload_rho(hipeng *e, const c_float *rho_vec) {
   if (e->m > 0) {
     if (!rho_vec) return HIPENG_ERR_ARG;
     if (upload_vec(e, e->c.rho, rho_vec, e->m)) return HIPENG_ERR_HIP;
-    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c);
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
   }
   hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
   HIPCHK(hipGetLastError());
@@ -1799,7 +1836,7 @@ extern "C" int hipeng_upload_matrices(hipeng *e, const csc *P, const csc *A) {
   // z~ = A x~ for the new A so that the PCG warm start stays consistent
   if (e->m > 0) {
     hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, e->c.va, e->c.zt, 0);
-    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c);
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1815,7 +1852,7 @@ extern "C" int hipeng_matrices_changed(hipeng *e) {
   hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
   if (e->m > 0) {
     hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, e->c.va, e->c.zt, 0);
-    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c);
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1832,6 +1869,7 @@ extern "C" int hipeng_cold_start(hipeng *e) {
   HIPCHK(hipMemsetAsync(e->c.z, 0, std::max<size_t>(e->m, 1) * sizeof(double), e->stream));
   HIPCHK(hipMemsetAsync(e->c.zt, 0, std::max<size_t>(e->m, 1) * sizeof(double), e->stream));
   e->calibrated = false;   // the first solve from zero needs far more PCG iterations than the steady state
+  e->start_dirty = true;
   return 0;
 }
 
@@ -1844,12 +1882,13 @@ extern "C" int hipeng_set_iterates(hipeng *e, const c_float *x, const c_float *y
     if (upload_vec(e, e->c.xy, x, n)) return HIPENG_ERR_HIP;
     // PCG warm start x~ = x ; z = A x ; z~ = z   (osqp_warm_start, osqp.c:960-963)
     HIPCHK(hipMemcpyAsync(e->c.va, e->c.xy, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    e->start_dirty = true;
     if (m > 0) {
       hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, e->c.xy, e->c.z, 0);
       HIPCHK(hipMemcpyAsync(e->c.zt, e->c.z, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     }
   }
-  if (m > 0) hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c);
+  if (m > 0) hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
@@ -1862,7 +1901,7 @@ extern "C" int hipeng_set_z(hipeng *e, const c_float *z) {
   if (m > 0 && z) {
     if (upload_vec(e, e->c.z, z, m)) return HIPENG_ERR_HIP;
     HIPCHK(hipMemcpyAsync(e->c.zt, e->c.z, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c);
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1947,6 +1986,7 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   s.iters_max = 0;
   HIPCHK(hipMemcpyAsync(e->c.st, &s, sizeof(State), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->start_dirty) { if (reset_start(e)) return HIPENG_ERR_HIP; e->start_dirty = false; }
   const long long start = s.admm_done;
   long long remaining = count;
   const int cap = std::max(2, e->prm.pcg_max_iter);
@@ -2091,7 +2131,7 @@ extern "C" int hipeng_kkt_solve(hipeng *e, c_float *b) {
   if (m > 0) {
     // stage b2 in z, y = 0  =>  k_refresh_m writes vb = rho*z - y = rho.b2
     if (upload_vec(e, e->c.z, b + n, m)) return HIPENG_ERR_HIP;
-    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c);
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
   }
   e->prm.use_cvec = 1;
   if (push_params(e)) return HIPENG_ERR_HIP;
