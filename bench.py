@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=2000, help="size of the bounded CPU sample (m = 2n)")
     ap.add_argument("--batch", type=int, default=1024, help="MPC batch size for the QPs/s leg (0 = skip)")
     ap.add_argument("--no-inexact", action="store_true", help="skip the opt-in inexact-mode leg (shorter traces under rocprofv3)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / config 5 legs")
     ap.add_argument("--cpu-batch-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     return ap.parse_args()
@@ -87,6 +88,47 @@ def kernel_roofline(solver, reps=300):
                      "dependent-kernel boundary); the 8 MB working set is L2/Infinity-Cache resident" % reps,
                 all_kernels=[dict(kernel=r["kernel"], usec=round(r["usec"], 3), gbs=round(r["gbs"], 2))
                              for r in rows])
+
+
+def other_configs(eps):
+    """BASELINE configs 3 (Lasso, 7.5 M non-zeros) and 5 (portfolio, 400 dense blocks + a 50 000-entry
+    row) at full size: the HBM-bound cases.  One cold solve each (C3 capped at 200 iterations),
+    plus the graph-timed PCG kernels with their algorithmic bytes."""
+    import osqp_amd
+    from osqp_amd.problems import lasso_qp, portfolio_qp
+    L = osqp_amd.lib()
+    L.hipeng_time_kernel.restype = C.c_int
+    L.hipeng_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.hipeng_kernel_bytes.restype = C.c_int
+    L.hipeng_kernel_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    out = {}
+    for name, make, kw in (("config5_portfolio_n50000", lambda: portfolio_qp(), {}),
+                           ("config3_lasso_5000x10000", lambda: {k: v for k, v in lasso_qp().items() if k in "PqAlu"}, dict(max_iter=200))):
+        pb = make()
+        t0 = time.perf_counter()
+        s = osqp_amd.OSQP().setup(**pb, eps_abs=eps, eps_rel=eps, **kw)
+        ts = time.perf_counter() - t0
+        t0 = time.perf_counter(); r = s.solve(); tv = time.perf_counter() - t0
+        st = s.stats()
+        rows = []
+        # split mode (A dominated by long rows): k_cg_A runs as a vector-update launch (3) and an
+        # operator-apply launch (4); the apply carries the matrix stream
+        L.hipeng_is_split.restype = C.c_int; L.hipeng_is_split.argtypes = [C.c_void_p]
+        split = bool(L.hipeng_is_split(s.engine()))
+        for which, nm in (((3, "k_cg_A update-only"), (4, "k_cg_A apply-only")) if split else ((0, "k_cg_A"),)) + ((1, "k_cg_B"),):
+            us = C.c_double(); by = C.c_double()
+            L.hipeng_time_kernel(s.engine(), which, 100, C.byref(us)); L.hipeng_kernel_bytes(s.engine(), 0 if which in (3, 4) else which, C.byref(by))
+            if which == 3: by.value = 8.0 * 12 * s.n          # u,w,p,s,r,Minv,x read + p,s,r,x,u written
+            if which == 4: by.value -= 8.0 * 12 * s.n - 8.0 * s.n   # A stream + u gather + rho read, t written
+            rows.append(dict(kernel=nm, usec=round(us.value, 2), algorithmic_MB=round(by.value / 1e6, 2),
+                             gbs=round(by.value / us.value / 1e3, 1), frac_of_8TBs=round(by.value / us.value / 1e3 / HBM_PEAK_GBS, 4)))
+        out[name] = dict(n=int(s.n), m=int(s.m), nnzA=int(s.nnzA), nnzPtriu=int(s.nnzP), setup_s=round(ts, 3),
+                         status=r.info.status, admm_iters=int(r.info.iter), solve_s=round(tv, 4),
+                         admm_iters_per_s=round(r.info.iter / tv, 1),
+                         pcg_iters_per_admm_iter=round(st["pcg_iters_total"] / max(1, r.info.iter), 1),
+                         usec_per_pcg_iter=round(1e6 * tv / max(1, st["pcg_iters_total"]), 1), pcg_kernels=rows)
+        del s
+    return out
 
 
 def cpu_baseline(n, eps):
@@ -336,6 +378,8 @@ def main():
                                    "note": "OSQP_AMD_PCG_ADAPTIVE=1; results agree with the strict mode only to the ADMM tolerance"}
         if world == 1:
             out["roofline"] = kernel_roofline(solver)
+            if not a.no_configs:
+                out["other_configs"] = other_configs(a.eps)
             if not a.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.eps)
         if batch is not None:

@@ -136,6 +136,7 @@ int hipeng_spmv(hipeng *e, int which, const c_float *x, c_float *y);
 int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec);
 /* Algorithmic bytes of one launch of the kernels above. */
 int hipeng_kernel_bytes(hipeng *e, int which, double *bytes);
+int hipeng_is_split(hipeng *e);   /* k_cg_A as two launches (update-only + apply-only)? */
 
 #ifdef __cplusplus
 }

@@ -2206,6 +2206,9 @@ extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) 
   return 0;
 }
 
+// 1 if the vector update and the operator apply of k_cg_A run as two launches (A dominated by long rows)
+extern "C" int hipeng_is_split(hipeng *e) { return e && e->split && e->variant == 1 ? 1 : 0; }
+
 extern "C" int hipeng_kernel_bytes(hipeng *e, int which, double *bytes) {
   if (!e || !bytes) return HIPENG_ERR_ARG;
   const double n = e->n, m = e->m;
