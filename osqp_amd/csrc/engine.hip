@@ -316,6 +316,40 @@ __device__ __forceinline__ double wave_row_dot(const DevMat &Mx, int ka, int kb,
   return wave_sum((s0 + s1) + (s2 + s3));      // valid in lane 0
 }
 
+// y = P_b x_b for one dense diagonal block by the whole workgroup.  P_b is symmetric, so
+// y_r = sum_j P_b[j][r] x_j: lane r walks DOWN column r while the wavefront reads row j
+// contiguously (1 KB, fully coalesced); x_j is uniform.  Wavefront w takes the rows
+// j = w, w+4, ...; every load of the block is issued before anything is consumed (<= 32 rows
+// per wavefront); the four partial vectors meet in LDS.  No index loads, no gathers.
+// Returns y_r for r = threadIdx.x < b (0 otherwise); scratch: 5*DENSE_MAX doubles, x_b is left
+// in scratch[4*DENSE_MAX ...].  Ends with a barrier; the caller adds one before reusing scratch.
+__device__ __forceinline__ double dense_block_mv(const DenseP &dP, const DenseBlk d, const double *x, double *scratch) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double *dv = dP.val + d.off;
+  const bool h0 = lane < d.b, h1 = lane + 64 < d.b;
+  double v0[DENSE_MAX / 4], v1[DENSE_MAX / 4];
+#pragma unroll
+  for (int q = 0; q < DENSE_MAX / 4; ++q) {
+    const int j = w + 4 * q;
+    const double *row = dv + (size_t)j * d.b;
+    v0[q] = (j < d.b && h0) ? row[lane] : 0.0;
+    v1[q] = (j < d.b && h1) ? row[lane + 64] : 0.0;
+  }
+  double *xl = scratch + 4 * DENSE_MAX;
+  if ((int)threadIdx.x < DENSE_MAX) xl[threadIdx.x] = (int)threadIdx.x < d.b ? x[d.c0 + threadIdx.x] : 0.0;
+  __syncthreads();
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int q = 0; q < DENSE_MAX / 4; ++q) {
+    const double u = xl[min(w + 4 * q, DENSE_MAX - 1)];
+    a0 += v0[q] * u; a1 += v1[q] * u;
+  }
+  scratch[w * DENSE_MAX + lane] = a0; scratch[w * DENSE_MAX + 64 + lane] = a1;
+  __syncthreads();
+  const int r = threadIdx.x;
+  return r < d.b ? (scratch[r] + scratch[DENSE_MAX + r]) + (scratch[2 * DENSE_MAX + r] + scratch[3 * DENSE_MAX + r]) : 0.0;
+}
+
 #define LDS_DECL(NV)                                   \
   __shared__ double lprod[(NV) * MAX_CHUNK];           \
   __shared__ double red[16]
@@ -332,26 +366,48 @@ __device__ __forceinline__ double wave_row_dot(const DevMat &Mx, int ka, int kb,
 // iterates move smoothly: ADMM iterates follow a linear recurrence, so 2 x~_k - x~_{k-1} is 2-10x
 // closer to x~_{k+1} than x~_k is), preconditioned residual and the three start-up dot
 // products.  One dual-stream pass over M.
+template <bool DENSE>
 __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
   State *st = c.st;
   if (st->stalled) { if (blockIdx.x == 0 && threadIdx.x == 0) st->run = 0; return; }
   LDS_DECL(2);
   const Params prm = *c.prm;
   double prz = 0, prr = 0, pbb = 0;
-  for (int bi = blockIdx.x; bi < c.M.nblk; bi += gridDim.x) {
-    const RowBlk b = c.M.blk[bi];
+  // rows inside dense diagonal blocks of P: P x~0 by the block product, A' part from the remainder
+  // matrix; all other rows below (Mm = remainder matrix then, M itself otherwise)
+  const DevMat &Mm = DENSE ? c.Mk : c.M;
+  if (DENSE)
+  for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
+    const DenseBlk d = c.dP.blk[db];
+    double sA = dense_block_mv(c.dP, d, c.vx, lprod);
+    if ((int)threadIdx.x < d.b) {
+      const int j = d.c0 + threadIdx.x;
+      double sB = 0.0;
+      for (int k = Mm.rowptr[j]; k < Mm.rowptr[j + 1]; ++k) { const int cc = Mm.col[k]; const double v = Mm.val[k]; sA += v * c.vx[cc]; sB += v * c.vb[cc]; }
+      const double base = prm.use_cvec ? c.cvec[j] : (prm.sigma * c.xy[j] - c.q[j]);
+      const double bj = base + sB;
+      const double rj = bj - prm.sigma * c.vx[j] - sA;
+      const double zj = c.minv[j] * rj;
+      c.init_r[(size_t)j * c.init_stride] = rj;
+      c.init_z[j] = zj;
+      prz += rj * zj; prr += rj * rj; pbb += bj * bj;
+    }
+    __syncthreads();
+  }
+  for (int bi = blockIdx.x; bi < Mm.nblk; bi += gridDim.x) {
+    const RowBlk b = Mm.blk[bi];
     const bool longrow = IS_LONG(b);
     if (!longrow) {
-      stage_products<2>(c.M, b, c.vx, c.vb, lprod, lprod + MAX_CHUNK);
+      stage_products<2>(Mm, b, c.vx, c.vb, lprod, lprod + MAX_CHUNK);
       __syncthreads();
     }
     for (int j = b.r0 + (longrow ? 0 : threadIdx.x); j < b.r1; j += (longrow ? 1 : TB)) {
       double sA, sB;
       if (longrow) {
-        sA = long_row_dot(c.M, b.k0, b.k1, c.vx, red);
-        sB = long_row_dot(c.M, b.k0, b.k1, c.vb, red);
+        sA = long_row_dot(Mm, b.k0, b.k1, c.vx, red);
+        sB = long_row_dot(Mm, b.k0, b.k1, c.vb, red);
       } else {
-        const int a0 = c.M.rowptr[j] - b.k0, a1 = c.M.rowptr[j + 1] - b.k0;
+        const int a0 = Mm.rowptr[j] - b.k0, a1 = Mm.rowptr[j + 1] - b.k0;
         sA = row_sum(lprod, a0, a1);
         sB = row_sum(lprod + MAX_CHUNK, a0, a1);
       }
@@ -822,41 +878,15 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
       gc[j].w = wj; pg += rj * uj; pd += wj * uj; prr += rj * rj;
     }
   }
-  // dense diagonal blocks of P, one workgroup per block.  P_b is symmetric, so
-  // y_r = sum_j P_b[j][r] u_j: lane r walks DOWN column r while the wavefront reads row j
-  // contiguously (1 KB, fully coalesced); u_j is uniform.  Wavefront w takes the rows
-  // j = w, w+4, ...; the four partial vectors meet in LDS.  No index loads, no gathers.
+  // dense diagonal blocks of P, one workgroup per block
   if (DENSE)
   for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
     const DenseBlk d = c.dP.blk[db];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const double *dv = c.dP.val + d.off;
-    const bool h0 = lane < d.b, h1 = lane + 64 < d.b;
-    // every load of the block is issued before anything is consumed: <= 32 rows per wavefront
-    double v0[DENSE_MAX / 4], v1[DENSE_MAX / 4];
-#pragma unroll
-    for (int q = 0; q < DENSE_MAX / 4; ++q) {
-      const int j = w + 4 * q;
-      const double *row = dv + (size_t)j * d.b;
-      v0[q] = (j < d.b && h0) ? row[lane] : 0.0;
-      v1[q] = (j < d.b && h1) ? row[lane + 64] : 0.0;
-    }
-    double *ul = lprod + 4 * DENSE_MAX;                 // u of the block, staged for broadcast reads
-    if ((int)threadIdx.x < DENSE_MAX) ul[threadIdx.x] = (int)threadIdx.x < d.b ? c.ut[d.c0 + threadIdx.x] : 0.0;
-    __syncthreads();
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-    for (int q = 0; q < DENSE_MAX / 4; ++q) {
-      const double u = ul[min(w + 4 * q, DENSE_MAX - 1)];
-      a0 += v0[q] * u; a1 += v1[q] * u;
-    }
-    lprod[w * DENSE_MAX + lane] = a0; lprod[w * DENSE_MAX + 64 + lane] = a1;
-    __syncthreads();
+    double acc = dense_block_mv(c.dP, d, c.ut, lprod);
     if ((int)threadIdx.x < d.b) {
-      const int r = threadIdx.x, jrow = d.c0 + r;
-      double acc = (lprod[r] + lprod[DENSE_MAX + r]) + (lprod[2 * DENSE_MAX + r] + lprod[3 * DENSE_MAX + r]);
+      const int jrow = d.c0 + threadIdx.x;
       for (int k = c.Mk.rowptr[jrow]; k < c.Mk.rowptr[jrow + 1]; ++k) acc += c.Mk.val[k] * c.ut[c.Mk.col[k]];   // A' part
-      const double uj = ul[r], wj = acc + sigma * uj, rj = gc[jrow].r;
+      const double uj = lprod[4 * DENSE_MAX + threadIdx.x], wj = acc + sigma * uj, rj = gc[jrow].r;
       gc[jrow].w = wj; pg += rj * uj; pd += wj * uj; prr += rj * rj;
     }
     __syncthreads();
@@ -1909,6 +1939,10 @@ extern "C" int hipeng_set_z(hipeng *e, const c_float *z) {
 }
 
 // ---- graphs ---------------------------------------------------------------
+static void launch_init(hipeng *e) {
+  if (e->c.dP.nblk) hipLaunchKernelGGL(k_pcg_init<true>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c);
+  else hipLaunchKernelGGL(k_pcg_init<false>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c);
+}
 static void launch_cg_A(hipeng *e, int it, int flags) {
   hipLaunchKernelGGL(k_cg_A, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, it, flags);
   const int nhuge = e->c.A.nblk - e->c.A.nwave;
@@ -1941,7 +1975,7 @@ static int get_graph(hipeng *e, int K, bool cont, hipGraphExec_t *out) {
   hipGraphExec_t ge = nullptr;
   HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
   if (!cont) {
-    hipLaunchKernelGGL(k_pcg_init, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c);
+    launch_init(e);
     if (e->c.big) hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(1024), 0, e->stream, e->c);
     if (e->variant == 1) {   // operator apply on u0 (+ first convergence test), then w0 and the first dots
       launch_cg_A(e, -1, 8);
@@ -2175,7 +2209,7 @@ extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) 
   HIPCHK(hipSetDevice(e->device));
   const Ctx &c = e->c;
   auto one = [&](int it) {
-    if (which == 5) { hipLaunchKernelGGL(k_pcg_init, dim3(c.gridM), dim3(TB), 0, e->stream, c); return; }   // first kernel of an ADMM iteration
+    if (which == 5) { launch_init(e); return; }   // first kernel of an ADMM iteration
     if (e->variant == 1) {
       if (which == 0) launch_cg_A(e, it, 4);
       else if (which == 3) launch_cg_A(e, it, 4 | 16);
