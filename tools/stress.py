@@ -64,7 +64,7 @@ def make(rng, kind):
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     only = set(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else None
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", 2026)))
     kinds = ["sparse"] * 6 + ["longrows"] * 2 + ["blocks"] * 3 + ["huge"]
     bad = 0; t0 = time.time()
     for case in range(n_cases):

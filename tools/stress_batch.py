@@ -16,7 +16,7 @@ def rel(a, b):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     only = set(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else None
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", 99)))
     bad = 0
     for case in range(cases):
         n = int(rng.integers(3, 129)); m = int(rng.integers(1, min(400, 3 * n + 5)))
