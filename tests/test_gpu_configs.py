@@ -227,3 +227,40 @@ def test_tight_tolerance_on_ill_conditioned_system(gpu_lib, oracle_mod):
         assert rg.info.status == ro.info.status == "solved"
         assert abs(rg.info.iter - ro.info.iter) <= 25, (eps, rg.info.iter, ro.info.iter)   # at most one check interval apart
         assert _rel(rg.x, ro.x) < 1e-6
+
+
+def test_random_structures_solve_to_tolerance(gpu_lib, oracle_mod):
+    """A slice of tools/stress.py inside the suite: 24 random QPs cycling through short rows, long
+    rows (one wavefront each), dense diagonal blocks of P (with stray couplings) and huge rows
+    (sliced over the grid), random settings.  Asserted: same status as the oracle and, when
+    solved, KKT residuals of the returned point within the requested tolerances (size- and
+    trajectory-independent); iteration counts are compared where the system is well conditioned."""
+    import os, sys
+    import osqp_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import importlib
+    argv = sys.argv; sys.argv = argv[:1]
+    try:
+        stress = importlib.import_module("tools.stress")
+    finally:
+        sys.argv = argv
+    rng = np.random.default_rng(314)
+    kinds = ["sparse", "longrows", "blocks", "sparse", "blocks", "huge"]
+    same_iter = 0
+    for case in range(24):
+        kind = kinds[case % len(kinds)]
+        pb = stress.make(rng, kind)
+        eps = 1e-4
+        kw = dict(eps_abs=eps, eps_rel=eps)
+        if case % 3 == 1: kw["scaling"] = 0
+        if case % 4 == 2: kw["alpha"] = 1.3
+        if kind == "huge": kw["max_iter"] = 300
+        rg = osqp_amd.OSQP().setup(**pb, **kw).solve()
+        ro = oracle_mod.OracleOSQP().setup(**pb, **kw).solve()
+        assert rg.info.status == ro.info.status, (case, kind, rg.info.status, ro.info.status)
+        if rg.info.status == "solved":
+            pri, dua, ps, ds = _kkt(pb, rg)
+            assert pri <= eps + eps * ps + 1e-9 and dua <= eps + eps * ds + 1e-9, (case, kind, pri, dua)
+        same_iter += int(rg.info.iter == ro.info.iter)
+    assert same_iter >= 20          # ill-conditioned members may end a check interval apart
