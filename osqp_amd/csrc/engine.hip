@@ -110,6 +110,7 @@ struct Params {          // mutable scalars (host writes, kernels read)
   double sigma, alpha, eps_rel, eps_abs, cinv;
   int    pcg_max_iter, use_cvec, has_scaling, k_expect;   // k_expect: PCG iterations the host expects per solve
   double ex_theta;         // extrapolation of the PCG start vector (0 = plain warm start)
+  int    ex_h0, ex_h1;     // no extrapolation before iteration ex_h0 after a reset, half a step before ex_h1
 };
 
 struct Ctx {             // static pointers / sizes, passed by value
@@ -955,7 +956,7 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
   // iteration).  No extrapolation in the first iterations after a reset (the iterates still jump),
   // half a step for a while, then the full linear step.  hist_r is advanced by k_pcg_init only.
   const int hist = st->hist_r;
-  const double th = (hist < 5 ? 0.0 : (hist < 12 ? 0.5 : 1.0)) * prm.ex_theta;
+  const double th = (hist < prm.ex_h0 ? 0.0 : (hist < prm.ex_h1 ? 0.5 : 1.0)) * prm.ex_theta;
   const bool ex = c.vx != c.va;
   double *x = c.xy, *y = c.xy + c.n;
   for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
@@ -1691,7 +1692,8 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   e->prm.eps_rel = prm->pcg_eps_rel; e->prm.eps_abs = prm->pcg_eps_abs;
   e->prm.pcg_max_iter = (int)prm->pcg_max_iter; e->prm.cinv = 1.0;
   e->prm.use_cvec = 0; e->prm.has_scaling = 0; e->prm.k_expect = 1 << 30;
-  e->prm.ex_theta = 1.0;
+  e->prm.ex_theta = 1.0; e->prm.ex_h0 = 5; e->prm.ex_h1 = 12;
+  if (const char *x = getenv("OSQP_AMD_EXTRAP_SCHED")) sscanf(x, "%d,%d", &e->prm.ex_h0, &e->prm.ex_h1);
   if (const char *x = getenv("OSQP_AMD_EXTRAP")) e->prm.ex_theta = atof(x);
   if (e->variant != 1 || e->prm.ex_theta == 0.0) { e->prm.ex_theta = 0.0; c.vx = c.va; }   // classic variant: plain warm start
   e->ex_theta0 = e->prm.ex_theta;
