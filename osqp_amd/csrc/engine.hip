@@ -1415,8 +1415,9 @@ static int pick_chunk(long long nnz, int nrows) {
   // consumer kernel re-reduces one dot partial per producer workgroup, so the
   // grid is kept near the CU count), full 2048-product chunks on large ones
   int chunk = 256;
-  while (chunk < MAX_CHUNK && nnz / chunk > 384) chunk <<= 1;
+  while (chunk < MAX_CHUNK && nnz / chunk > 640) chunk <<= 1;
   (void)nrows;
+  if (const char *x = getenv("OSQP_AMD_CHUNK")) { const int v = atoi(x); if (v >= 64 && v <= MAX_CHUNK) chunk = v; }   // tuning experiments
   return chunk;
 }
 
