@@ -2057,7 +2057,8 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     }
     if (e->trace) fprintf(stderr, "[osqp_amd] window: K=%d burst=%lld done=%lld iters_max=%d last=%d launches=%lld\n", e->K, burst, (long long)(s.admm_done - start), s.iters_max, s.iters_last, (long long)e->stats.graph_launches);
     // track the iteration count: shrink slowly, grow at once
-    const int want = s.iters_max + std::max(3, s.iters_max / 6);   // head-room against drift between windows
+    static const int khead = getenv("OSQP_AMD_KHEAD") ? atoi(getenv("OSQP_AMD_KHEAD")) : 3;   // tuning experiments
+    const int want = s.iters_max + std::max(khead, s.iters_max / 6);   // head-room against drift between windows
     const int Kn = next_K(want, cap);
     e->K = Kn;
     if (std::abs(e->prm.k_expect - s.iters_max) > 1) {
