@@ -127,6 +127,13 @@ def other_configs(eps):
                          admm_iters_per_s=round(r.info.iter / tv, 1),
                          pcg_iters_per_admm_iter=round(st["pcg_iters_total"] / max(1, r.info.iter), 1),
                          usec_per_pcg_iter=round(1e6 * tv / max(1, st["pcg_iters_total"]), 1), pcg_kernels=rows)
+        try:      # the CPU direct solver on the same problem, recorded once by tools/make_config{3,5}_golden.py
+            g = json.load(open(os.path.join(ROOT, "tests", "golden", name.split("_")[0] + "_oracle.json")))["info"]
+            out[name]["cpu_oracle_recorded"] = dict(admm_iters=g["iters"], admm_iters_per_s=round(g["its"], 2), setup_s=round(g["setup_s"], 1),
+                                                    solve_s=round(g["solve_s"], 1), cores=1,
+                                                    where="build container, full solve to eps 1e-4 (tests/golden/%s_oracle.json)" % name.split("_")[0])
+        except Exception:
+            pass
         del s
     return out
 

@@ -365,6 +365,41 @@ def test_full_size_config2_matches_oracle_golden(gpu_lib):
     assert abs(r.info.dua_res - gi["dua"]) <= 1e-4 * gi["dua"] + 1e-9
 
 
+@pytest.mark.parametrize("pcg_rel, tol_obj, tol_xy", [(1e-10, 1e-4, 1e-4), (1e-12, 1e-6, 1e-6)], ids=["pcg1e-10", "pcg1e-12"])
+@pytest.mark.parametrize("cfg", ["config5", "config3"])
+def test_full_size_config3_config5_match_oracle_golden(gpu_lib, cfg, pcg_rel, tol_obj, tol_xy):
+    """BASELINE configs 5 (portfolio, n = 50000: 400 dense 125x125 blocks of P through the dense
+    block kernels, a 50 000-entry budget row through the sliced huge-row path) and 3 (Lasso,
+    7.5 M non-zeros, rows of 751 entries) at full size against the CPU oracle's results
+    (tests/golden/config{5,3}_oracle.json; generators tools/make_config{5,3}_golden.py; the
+    Lasso run took the oracle 77 s to factorise and 282 s to solve): same iteration count
+    (325 / 1875) and rho updates.  Both families carry equality rows at rho_eq = 1e3 rho, so
+    x, y and the objective agree to about cond * pcg_eps_rel: 1e-4 relative at the default
+    1e-10, 1e-6 at 1e-12 (same note as in test_gpu_configs)."""
+    import json, os
+    import osqp_amd
+    from conftest import GOLDEN
+    from osqp_amd.problems import portfolio_qp, lasso_qp
+    g = json.load(open(os.path.join(GOLDEN, cfg + "_oracle.json")))
+    if cfg == "config5":
+        pb, kw, step = portfolio_qp(), dict(adaptive_rho_interval=100), 50
+    else:
+        pb, kw, step = {k: v for k, v in lasso_qp().items() if k in "PqAlu"}, {}, 20
+    old = osqp_amd.engine_options()["pcg_eps_rel"]
+    osqp_amd.set_engine_options(pcg_eps_rel=pcg_rel)
+    try:
+        r = osqp_amd.OSQP().setup(**pb, eps_abs=1e-4, eps_rel=1e-4, **kw).solve()
+    finally:
+        osqp_amd.set_engine_options(pcg_eps_rel=old)
+    gi = g["info"]
+    assert r.info.status == gi["status"] == "solved"
+    assert r.info.iter == gi["iters"] and r.info.rho_updates == gi["rho_updates"]
+    assert abs(r.info.obj_val - gi["obj"]) <= tol_obj * abs(gi["obj"])
+    xs, ys = np.array(g["x_sub"]), np.array(g["y_sub"])
+    assert np.abs(r.x[::step] - xs).max() <= tol_xy * max(1.0, g["x_inf"])
+    assert np.abs(r.y[::step] - ys).max() <= tol_xy * max(1.0, g["y_inf"])
+
+
 def test_non_cvx_golden(gpu_lib):
     """tests/non_cvx/test_non_cvx.h:26-58: indefinite P.  With sigma = 1e-6 the reduced
     matrix is not positive definite and setup must fail with OSQP_NONCVX_ERROR (5) -- the
