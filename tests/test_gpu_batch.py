@@ -97,6 +97,23 @@ def test_full_batch_1024_properties(gpu_lib):
     assert np.all(dua <= 1e-3 + 1e-3 * np.maximum(np.abs(r.x @ P).max(axis=1), np.abs(r.y @ A).max(axis=1)) + 1e-9)
 
 
+def test_full_batch_1024_matches_oracle(gpu_lib, oracle_mod):
+    """BASELINE config 4 at full size, every one of the 1024 QPs against its own oracle solve:
+    status, iteration count and rho updates identical; x, y 1e-6 relative; objective 1e-8."""
+    import osqp_amd
+    from osqp_amd.problems import mpc_batch
+    s, Q, L, U = mpc_batch(batch=1024)
+    r = osqp_amd.BatchOSQP().setup(s["P"], s["A"], Q, L, U).solve()
+    worst_x = worst_y = 0.0
+    for b in range(1024):
+        ro = oracle_mod.OracleOSQP().setup(P=s["P"], q=Q[b], A=s["A"], l=L[b], u=U[b]).solve()
+        assert r.status_val[b] == ro.info.status_val == 1, b
+        assert r.iter[b] == ro.info.iter and r.rho_updates[b] == ro.info.rho_updates, (b, r.iter[b], ro.info.iter)
+        worst_x = max(worst_x, _rel(r.x[b], ro.x)); worst_y = max(worst_y, _rel(r.y[b], ro.y))
+        assert abs(r.obj_val[b] - ro.info.obj_val) <= 1e-8 * max(1.0, abs(ro.info.obj_val)), b
+    assert worst_x < 1e-6 and worst_y < 1e-6, (worst_x, worst_y)
+
+
 def test_dispatch_order_does_not_change_results(gpu_lib, monkeypatch):
     """From the second solve on, workgroups take the QPs longest-first (by the previous
     solve's iteration counts).  Scheduling only: every solve of a sequence must be
