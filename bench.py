@@ -73,7 +73,7 @@ def kernel_roofline(solver, reps=300):
     # --pmc WRITE_SIZE, separate runs; profiles/r01_*_pmc_and_durations.json), same workload only
     traffic = None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_and_durations.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_and_durations.json")))
         if (solver.n, solver.m) == (10000, 20000):
             k = [v for kk, v in prof["kernels"].items() if kk.startswith(dom["kernel"])][0]
             traffic = round(1024.0 * (k["FETCH_SIZE_KB"]["median"] + k["WRITE_SIZE_KB"]["median"]), 1)
