@@ -300,13 +300,22 @@ def main():
     dev_id = local_rank % ndev          # == local_rank on a real multi-GPU node
     torch.cuda.set_device(dev_id)
     coll_dev = torch.device("cuda", dev_id) if a.backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):     # BENCH_FORCE_DIST=1: exercise the collectives with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=coll_dev)
-        else:
-            dist.init_process_group(a.backend)
+        # RCCL writes a version banner to stdout when a communicator is created: stdout carries the
+        # one JSON line only, so the banner goes to stderr (fd-level, the banner comes from C code)
+        sys.stdout.flush()
+        saved = os.dup(1); os.dup2(2, 1)
+        try:
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", device_id=coll_dev)
+            else:
+                dist.init_process_group(a.backend)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush(); os.dup2(saved, 1); os.close(saved)
     import osqp_amd
     from osqp_amd.problems import random_sparse_qp
     osqp_amd.set_engine_options(device=dev_id)
