@@ -681,9 +681,18 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->tol2 = tol2; st->gam[1] = 0.0; st->alp[1] = 0.0; }
   } else {
     const double rr = sums[0], gam = sums[1], del = sums[2];
-    first = gam_old == 0.0;            // the pre pass zeroes gam[1]: first update of this solve
+    const bool fresh = gam_old == 0.0;   // the pre pass zeroes gam[1]: first update of this solve
+    first = fresh;
     if (first) { beta = 0.0; alpha = gam / del; }
-    else { beta = gam / gam_old; alpha = gam / (del - beta * gam / alp_old); }
+    else {
+      beta = gam / gam_old;
+      const double den = del - beta * gam / alp_old;
+      // The two-term recurrence for alpha loses positivity at the rounding floor of an
+      // ill-conditioned system although u'Ku > 0: restart the directions from u (p = u, s = w)
+      // instead of giving the solve up.
+      if (!(den > 0.0) && del > 0.0) { first = true; beta = 0.0; alpha = gam / del; }
+      else alpha = gam / den;
+    }
     if (bench) { beta = 0.5; alpha = 1e-3; }
     const bool conv = rr <= tol2;
     const bool bad = !(alpha > 0.0) || !(del > 0.0);      // breakdown / negative curvature
@@ -699,7 +708,7 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
     for (int j = j0; j < c.n; j += gridDim.x * TB) {
       double uj, wj, po, so, ro, xo, mi;
       if (j == j0) { uj = o_u; wj = o_w; po = o_p; so = o_s; ro = o_r; xo = o_x; mi = o_m; }
-      else { const G4 g = gold[j]; uj = c.ut[j]; wj = g.w; po = c.pdir[j]; so = g.s; ro = g.r; xo = first ? c.vx[j] : c.va[j]; mi = g.m; }
+      else { const G4 g = gold[j]; uj = c.ut[j]; wj = g.w; po = c.pdir[j]; so = g.s; ro = g.r; xo = fresh ? c.vx[j] : c.va[j]; mi = g.m; }
       const double pj = first ? uj : (uj + beta * po);
       const double sj = first ? wj : (wj + beta * so);
       const double rj = ro - alpha * sj;
