@@ -1375,7 +1375,7 @@ struct hipeng {
   double ex_theta0 = 1.0;    // OSQP_AMD_EXTRAP (0 disables the extrapolated PCG start)
   bool start_dirty = true;   // [x~ | rho z~] was rewritten from outside the loop: PCG start history is void
   int warm_windows = 0;   // windows since the last (re)calibration: bursts grow 1, 4, 8, then up to 64
-  bool trace = false;
+  int trace = 0;            // OSQP_AMD_TRACE: 1 = one line per window, 2 = every HIP call of the run loop
   hipeng_stats stats{};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   long long admm_done_seen = 0;
@@ -1669,7 +1669,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   {
     const char *v = getenv("OSQP_AMD_PCG_VARIANT");
     e->variant = v ? atoi(v) : 1;          // 1 = Chronopoulos-Gear (2 kernels / iteration), 0 = classic (3)
-    e->trace = getenv("OSQP_AMD_TRACE") != nullptr;
+    if (const char *t = getenv("OSQP_AMD_TRACE")) e->trace = std::max(1, atoi(t));
   }
   c.big = 0;   // experimental (OSQP_AMD_BIG=1): measured slower than the capped grid on config 3
   if (const char *bg = getenv("OSQP_AMD_BIG")) c.big = (atoi(bg) != 0 && e->variant == 1) ? 1 : 0;
@@ -1951,6 +1951,7 @@ extern "C" int hipeng_set_z(hipeng *e, const c_float *z) {
 }
 
 // ---- graphs ---------------------------------------------------------------
+#define TR2(e, ...) do { if ((e)->trace >= 2) { fprintf(stderr, "[osqp_amd:t2] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 static void launch_init(hipeng *e) {
   if (e->c.dP.nblk) hipLaunchKernelGGL(k_pcg_init<true>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c);
   else hipLaunchKernelGGL(k_pcg_init<false>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c);
@@ -1985,6 +1986,7 @@ static int get_graph(hipeng *e, int K, bool cont, hipGraphExec_t *out) {
   if (f != cache.end()) { *out = f->second; return 0; }
   hipGraph_t g = nullptr;
   hipGraphExec_t ge = nullptr;
+  TR2(e, "get_graph K=%d cont=%d: begin capture", K, (int)cont);
   HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
   if (!cont) {
     launch_init(e);
@@ -2002,7 +2004,9 @@ static int get_graph(hipeng *e, int K, bool cont, hipGraphExec_t *out) {
   if (e->c.A.nblk > e->c.A.nwave) hipLaunchKernelGGL(k_huge_dot, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, (const double *)e->c.va, 0);
   hipLaunchKernelGGL(k_admm_finalize, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c);
   HIPCHK(hipStreamEndCapture(e->stream, &g));
+  TR2(e, "get_graph: captured, instantiate");
   HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  TR2(e, "get_graph: instantiated");
   HIPCHK(hipGraphDestroy(g));
   cache[K] = ge;
   *out = ge;
@@ -2027,11 +2031,22 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   if (!e || count < 0) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   State s;
+  if (e->trace >= 2) {
+    if (const char *mp = getenv("OSQP_AMD_TRACE_MAPS")) {     // address map, to read a crash stack
+      static bool dumped = false;
+      if (!dumped) {
+        dumped = true;
+        if (FILE *in = fopen("/proc/self/maps", "r")) {
+          if (FILE *out = fopen(mp, "w")) { char buf[4096]; size_t k; while ((k = fread(buf, 1, sizeof buf, in)) > 0) fwrite(buf, 1, k, out); fclose(out); }
+          fclose(in);
+        }
+      }
+    }
+  }
+  TR2(e, "run_admm count=%lld: read_state", (long long)count);
   // reset the per-call maximum
   if (read_state(e, &s)) return HIPENG_ERR_HIP;
-  s.iters_max = 0;
-  HIPCHK(hipMemcpyAsync(e->c.st, &s, sizeof(State), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemsetAsync(&e->c.st->iters_max, 0, sizeof(int), e->stream));
   if (e->start_dirty) { if (reset_start(e)) return HIPENG_ERR_HIP; e->start_dirty = false; }
   const long long start = s.admm_done;
   long long remaining = count;
@@ -2044,9 +2059,12 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     static const int ramp[] = {1, 4, 8};
     const long long burst = std::min<long long>(remaining, e->warm_windows < 3 ? ramp[e->warm_windows] : 64);
     e->warm_windows++;
+    TR2(e, "launch burst=%lld K=%d", burst, e->K);
     for (long long i = 0; i < burst; i++) HIPCHK(hipGraphLaunch(ge, e->stream));
     e->stats.graph_launches += (c_int)burst;
+    TR2(e, "burst enqueued, read_state");
     if (read_state(e, &s)) return HIPENG_ERR_HIP;
+    TR2(e, "state read: done=%lld stalled=%d", (long long)(s.admm_done - start), s.stalled);
     while (s.stalled) {            // finish the stalled solve with more PCG iterations
       hipGraphExec_t gc;
       const int Kc = next_K(std::max(2 * e->K, 16), cap);
@@ -2061,8 +2079,7 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     remaining = count - (s.admm_done - start);
     call_max = std::max(call_max, s.iters_max);
     if (remaining > 0) {     // the next burst is sized from its predecessor alone: restart the device-side maximum
-      const int zero = 0;
-      HIPCHK(hipMemcpyAsync(&e->c.st->iters_max, &zero, sizeof(int), hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemsetAsync(&e->c.st->iters_max, 0, sizeof(int), e->stream));
     }
     if (e->trace) fprintf(stderr, "[osqp_amd] window: K=%d burst=%lld done=%lld iters_max=%d last=%d launches=%lld\n", e->K, burst, (long long)(s.admm_done - start), s.iters_max, s.iters_last, (long long)e->stats.graph_launches);
     // track the iteration count: shrink slowly, grow at once
