@@ -3,7 +3,7 @@
 // What runs here (all fp64, int32 indices, one HIP stream per engine):
 //   * the ADMM iteration of osqp_solve (reference src/osqp.c:356-370,
 //     src/auxil.c:161-225, src/proj.c:4-14) as hipGraph replays of
-//       k_pcg_init -> K x { k_pcg_Ap, k_pcg_Kp, k_pcg_update } -> k_admm_finalize
+//       k_pcg_init -> k_cg_A, k_cg_B (operator on u0) -> K x { k_cg_A, k_cg_B } -> k_admm_finalize
 //   * the linear solve of update_xz_tilde as an indirect method: Jacobi-PCG on
 //       (P + sigma I + A' diag(rho) A) x~ = sigma x - q + A'(rho.z - y)
 //     (docs/solver/index.rst:50-55 in the reference), then z~ = A x~
@@ -90,7 +90,7 @@ struct DenseP {
 // Written by kernels only; read by the host between windows.
 struct State {
   int    run;          // this ADMM iteration is active (written by the first kernel)
-  int    done;         // PCG converged (written by k_pcg_Ap)
+  int    done;         // PCG converged (written by k_cg_A)
   int    stalled;      // PCG ran out of unrolled iterations (written by finalize)
   int    neg_curv;     // p'Kp <= 0 seen
   int    iters[2];     // PCG iterations of the current solve (ping-pong on parity)
@@ -104,6 +104,7 @@ struct State {
   double tol2;
   double gam[2], alp[2];   // Chronopoulos-Gear scalars (ping-pong on parity)
   int    hist_r;           // ADMM iterations since the PCG start vector history was reset (k_pcg_init counts)
+  long long admm_target;   // k_pcg_init starts no new ADMM iteration once admm_done has reached this
 };
 
 struct Params {          // mutable scalars (host writes, kernels read)
@@ -111,6 +112,7 @@ struct Params {          // mutable scalars (host writes, kernels read)
   int    pcg_max_iter, use_cvec, has_scaling, k_expect;   // k_expect: PCG iterations the host expects per solve
   double ex_theta;         // extrapolation of the PCG start vector (0 = plain warm start)
   int    ex_h0, ex_h1;     // no extrapolation before iteration ex_h0 after a reset, half a step before ex_h1
+  int    no_restart;       // setup-time convexity probe: any loss of positivity counts as negative curvature
 };
 
 struct Ctx {             // static pointers / sizes, passed by value
@@ -121,17 +123,17 @@ struct Ctx {             // static pointers / sizes, passed by value
   int gridA, gridM;      // launch grids (>=1) of row kernels over A / over M
   double *xy, *z, *zt, *va, *vb, *q, *l, *u, *rho, *rhoinv, *minv, *pdiag;
   double *r, *zz, *kp, *pt0, *pt1, *dxy, *dy, *cvec;
-  double *init_r, *init_z;        // where k_pcg_init puts r0 and Minv r0 (variant dependent)
+  double *init_r, *init_z;        // where k_pcg_init puts r0 and Minv r0
   double *vx, *vold;               // PCG start vector [x~0 | rho z~0] (extrapolated) and the previous [x~ | rho z~]
-  double *pdir, *ut;               // Chronopoulos-Gear variant: p, [u|t]
+  double *pdir, *ut;               // Chronopoulos-Gear PCG: p, [u|t]
   G4     *g4;                      // ... and {r, w, s, Minv} records, ping-ponged on parity (2n)
   int     init_stride;             // element stride of init_r (4 when it points into g4)
   double *D, *Dinv, *E, *Einv;
   double *part_rz, *part_rr, *part_bb, *part_pkp, *part_s0, *part_s1, *part_s2, *part_gam, *part_del;
+  const double *fin_rr;  // where k_admm_finalize finds the partials of the last ||r||^2, and how many
+  int fin_cnt;
   double *scal;          // reduction outputs (see SC_* below)
   double *part_h;        // huge A rows: [row][workgroup of k_cg_A] partial dots
-  double *redout;        // big mode: [rr, gamma, delta, bb] reduced by k_reduce_parts
-  int big;               // grids above MAX_PARTS workgroups: partials are reduced by a one-workgroup kernel
   State  *st;
   const Params *prm;
 };
@@ -370,7 +372,11 @@ __device__ __forceinline__ double dense_block_mv(const DenseP &dP, const DenseBl
 template <bool DENSE>
 __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
   State *st = c.st;
-  if (st->stalled) { if (blockIdx.x == 0 && threadIdx.x == 0) st->run = 0; return; }
+  // A solve that ran out of unrolled PCG iterations (`stalled`, raised by k_admm_finalize) is continued by
+  // this graph launch: no new right-hand side, the iteration kernels below pick the recurrences up where they
+  // stopped (K is even, so the parity of every ping-pong buffer is preserved).
+  if (st->stalled) return;
+  if (st->admm_done >= st->admm_target) { if (blockIdx.x == 0 && threadIdx.x == 0) st->run = 0; return; }
   LDS_DECL(2);
   const Params prm = *c.prm;
   double prz = 0, prr = 0, pbb = 0;
@@ -434,141 +440,6 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
   }
 }
 
-// PCG step 1: convergence test, beta, direction p = zz + beta p_old (fused into
-// the gather and written once per element), t = rho . (A p).
-// flags: bit0 = first iteration of a solve, bit1 = first kernel of a
-// "continue" graph (runs only while stalled), bit2 = benchmark (no early exit,
-// fixed beta).
-// Scalars that a kernel both reads and updates are ping-ponged on the parity of
-// `it` (rz[], iters[]) so that a late workgroup never observes a value written
-// by workgroup 0 of the same launch.
-__global__ void __launch_bounds__(TB) k_pcg_Ap(Ctx c, int it, int flags) {
-  State *st = c.st;
-  const bool first = flags & 1, cont = flags & 2, bench = flags & 4;
-  if (cont) {
-    const int act = st->stalled;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->run = act;
-    if (!act) return;
-  } else if (!bench && (!st->run || st->done)) return;
-  LDS_DECL(1);
-  const Params prm = *c.prm;
-  double sums[3];
-  reduce_parts<3>(c.part_rr, c.part_rz, c.part_bb, c.gridM, red, sums);
-  const double rr = sums[0], rz_new = sums[1];
-  const int iters_prev = st->iters[(it + 1) & 1];
-  double tol2, beta;
-  if (first) {
-    tol2 = fmax(prm.eps_rel * prm.eps_rel * sums[2], prm.eps_abs * prm.eps_abs);
-    beta = 0.0;
-  } else {
-    tol2 = st->tol2;
-    beta = rz_new / st->rz[(it + 1) & 1];
-  }
-  if (bench) beta = 0.5;
-  const bool conv = rr <= tol2;
-  const bool giveup = iters_prev >= prm.pcg_max_iter || st->neg_curv;
-  if (!bench && (conv || giveup)) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      st->done = conv ? 1 : 2;
-      if (first) { st->tol2 = tol2; st->rz[it & 1] = rz_new; }
-    }
-    return;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    st->rz[it & 1] = rz_new;
-    if (first) st->tol2 = tol2;
-    st->iters[it & 1] = iters_prev + 1;
-  }
-  const double *pold = (it & 1) ? c.pt0 : c.pt1;
-  double *pnew = (it & 1) ? c.pt1 : c.pt0;
-  // own slice of the new direction
-  for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB)
-    pnew[j] = first ? c.zz[j] : (c.zz[j] + beta * pold[j]);
-  for (int bi = blockIdx.x; bi < c.A.nblk; bi += gridDim.x) {
-    const RowBlk b = c.A.blk[bi];
-    const int cnt = b.k1 - b.k0;
-    if (IS_LONG(b)) {   // single long row
-      double s = 0.0;
-      for (int k = b.k0 + threadIdx.x; k < b.k1; k += TB) {
-        const int cc = c.A.col[k];
-        const double pv = first ? c.zz[cc] : (c.zz[cc] + beta * pold[cc]);
-        s += c.A.val[k] * pv;
-      }
-      s = block_sum(s, red);
-      if (threadIdx.x == 0) pnew[c.n + b.r0] = c.rho[b.r0] * s;
-    } else {
-      for (int k = threadIdx.x; k < cnt; k += TB) {
-        const int cc = c.A.col[b.k0 + k];
-        const double pv = first ? c.zz[cc] : (c.zz[cc] + beta * pold[cc]);
-        lprod[k] = c.A.val[b.k0 + k] * pv;
-      }
-      __syncthreads();
-      for (int i = b.r0 + threadIdx.x; i < b.r1; i += TB) {
-        const double s = row_sum(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0);
-        pnew[c.n + i] = c.rho[i] * s;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// PCG step 2: Kp = P p + sigma p + A' t, and the partials of p'Kp.
-__global__ void __launch_bounds__(TB) k_pcg_Kp(Ctx c, int it, int flags) {
-  State *st = c.st;
-  if (!(flags & 4) && (!st->run || st->done)) return;
-  LDS_DECL(1);
-  const double sigma = c.prm->sigma;
-  const double *pt = (it & 1) ? c.pt1 : c.pt0;
-  double ppkp = 0.0;
-  for (int bi = blockIdx.x; bi < c.M.nblk; bi += gridDim.x) {
-    const RowBlk b = c.M.blk[bi];
-    if (IS_LONG(b)) {
-      const double s = long_row_dot(c.M, b.k0, b.k1, pt, red);
-      if (threadIdx.x == 0) {
-        const double pj = pt[b.r0], kpj = s + sigma * pj;
-        c.kp[b.r0] = kpj; ppkp += pj * kpj;
-      }
-    } else {
-      stage_products<1>(c.M, b, pt, nullptr, lprod, nullptr);
-      __syncthreads();
-      for (int j = b.r0 + threadIdx.x; j < b.r1; j += TB) {
-        const double s = row_sum(lprod, c.M.rowptr[j] - b.k0, c.M.rowptr[j + 1] - b.k0);
-        const double pj = pt[j], kpj = s + sigma * pj;
-        c.kp[j] = kpj;
-        ppkp += pj * kpj;
-      }
-    }
-    __syncthreads();
-  }
-  ppkp = block_sum(ppkp, red);
-  if (threadIdx.x == 0) c.part_pkp[blockIdx.x] = ppkp;
-}
-
-// PCG step 3: alpha, x~ += alpha p, r -= alpha Kp, zz = Minv r, partials of r'zz, r'r.
-__global__ void __launch_bounds__(TB) k_pcg_update(Ctx c, int it, int flags) {
-  State *st = c.st;
-  const bool bench = flags & 4;
-  if (!bench && (!st->run || st->done)) return;
-  __shared__ double red[16];
-  double pkp[1];
-  reduce_parts<1>(c.part_pkp, nullptr, nullptr, c.gridM, red, pkp);
-  double alpha = 0.0;
-  if (bench) alpha = 1e-3;
-  else if (pkp[0] > 0.0) alpha = st->rz[it & 1] / pkp[0];
-  else if (blockIdx.x == 0 && threadIdx.x == 0) st->neg_curv = 1;
-  const double *pt = (it & 1) ? c.pt1 : c.pt0;
-  double prz = 0, prr = 0;
-  for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
-    c.va[j] += alpha * pt[j];
-    const double rj = c.r[j] - alpha * c.kp[j];
-    const double zj = c.minv[j] * rj;
-    c.r[j] = rj; c.zz[j] = zj;
-    prz += rj * zj; prr += rj * rj;
-  }
-  prz = block_sum(prz, red); prr = block_sum(prr, red);
-  if (threadIdx.x == 0) { c.part_rz[blockIdx.x] = prz; c.part_rr[blockIdx.x] = prr; }
-}
-
 // ---------------------------------------------------------------------------
 // Chronopoulos-Gear PCG: two kernels per iteration instead of three.
 //   u = Minv r, w = K u, gamma = (r,u), delta = (w,u)
@@ -579,38 +450,44 @@ __global__ void __launch_bounds__(TB) k_pcg_update(Ctx c, int it, int flags) {
 // expression, hence the same bits, as the value the owner stores); r and s are
 // ping-ponged on the parity of `it` so gathers never see half-updated data.
 // k_cg_B applies w = [P|A'][u;t] + sigma u and emits the three dot partials.
-// flags: bit1 = first kernel of a "continue" graph, bit2 = benchmark,
-//        bit3 = "pre" pass (pure operator apply on u0, first convergence test)
+// flags: bit2 = benchmark, bit3 = "pre" pass (pure operator apply on u0, first convergence test),
+//        bit4 / bit5 = vector update only / operator apply only (split mode)
 // ---------------------------------------------------------------------------
 #define EPT (MAX_CHUNK / TB)
-#define BIG_GRID 8192    // workgroup cap in big mode (32 per CU)
 
-// Big mode only: fixed-order reduction of the four partial arrays to scalars, so
-// consumers read 4 doubles instead of re-reducing thousands of partials each.
-__global__ void __launch_bounds__(1024) k_reduce_parts(Ctx c) {
-  __shared__ double red[4][16];
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  for (int i = threadIdx.x; i < c.gridM; i += 1024) {
-    s0 += c.part_rr[i]; s1 += c.part_gam[i]; s2 += c.part_del[i]; s3 += c.part_bb[i];
+// Scalars of one Chronopoulos-Gear step from the three reduced dot products.
+struct CgStep { double alpha, beta; bool first, stop, conv, bad; };
+__device__ __forceinline__ CgStep cg_step(double rr, double gam, double del, double gam_old, double alp_old,
+                                          double tol2, int iters_prev, int neg, const Params &prm, bool bench) {
+  CgStep s;
+  s.first = gam_old == 0.0;              // the pre pass zeroes gam[1]: first update of this solve
+  s.bad = false;
+  if (s.first) { s.beta = 0.0; s.alpha = gam / del; }
+  else {
+    s.beta = gam / gam_old;
+    const double den = del - s.beta * gam / alp_old;     // = p'Kp in exact arithmetic
+    if (!(den > 0.0) && del > 0.0) {
+      // u'Ku > 0 but the two-term recurrence lost positivity.  Near the stop (||r|| within 1e4 of the
+      // tolerance) this is the rounding floor of an ill-conditioned system: restart the directions
+      // from u (p = u, s = w).  Anywhere else -- and always during the setup-time convexity probe --
+      // it is what an indefinite K produces, and is reported as negative curvature.
+      if (!prm.no_restart && rr <= 1e8 * tol2) { s.first = true; s.beta = 0.0; s.alpha = gam / del; }
+      else { s.alpha = gam / den; s.bad = true; }
+    } else s.alpha = gam / den;
   }
-  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) { red[0][w] = s0; red[1][w] = s1; red[2][w] = s2; red[3][w] = s3; }
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    double t = 0;
-    for (int k = 0; k < 16; ++k) t += red[threadIdx.x][k];
-    c.redout[threadIdx.x] = t;
-  }
+  if (bench) { s.beta = 0.5; s.alpha = 1e-3; s.bad = false; }
+  s.conv = rr <= tol2;
+  s.bad = s.bad || !(s.alpha > 0.0) || !(del > 0.0);      // breakdown / negative curvature
+  s.stop = !bench && (s.conv || iters_prev >= prm.pcg_max_iter || neg || s.bad);
+  return s;
 }
-
 __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   State *st = c.st;
-  const bool cont = flags & 2, bench = flags & 4, upd_only = flags & 16, apply_only = flags & 32;
+  const bool bench = flags & 4, upd_only = flags & 16, apply_only = flags & 32;
   const bool pre = (flags & 8) || apply_only;   // gather u directly (no recompute)
   // unrolled iterations beyond the expected count are almost always no-ops: look at the
   // flags first there instead of prefetching speculatively
-  if (!bench && !cont && it > c.prm->k_expect && (!st->run || st->done)) return;
+  if (!bench && it > c.prm->k_expect && (!st->run || st->done)) return;
   // ---- issue every independent load before looking at the flags ----
   const int stalled = st->stalled, run = st->run, done = st->done, neg = st->neg_curv;
   const int iters_prev = st->iters[(it + 1) & 1];
@@ -647,12 +524,9 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   }
   // dot-product partials of the previous kernel (pre: rr, bb ; else: rr, gamma, delta)
   double q0 = 0, q1 = 0, q2 = 0;
-  if (apply_only) {
-  } else if (!c.big) {
+  if (!apply_only) {
     const double *a1 = pre ? c.part_bb : c.part_gam;
     for (int i = threadIdx.x; i < c.gridM; i += TB) { q0 += c.part_rr[i]; q1 += a1[i]; if (!pre) q2 += c.part_del[i]; }
-  } else if (threadIdx.x == 0) {
-    q0 = c.redout[0]; q1 = pre ? c.redout[3] : c.redout[1]; q2 = pre ? 0.0 : c.redout[2];
   }
   const int j0 = blockIdx.x * TB + threadIdx.x;
   double o_u = 0, o_w = 0, o_p = 0, o_s = 0, o_r = 0, o_x = 0, o_m = 0;
@@ -660,10 +534,7 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
     const G4 g = gold[j0];
     o_u = c.ut[j0]; o_w = g.w; o_p = c.pdir[j0]; o_s = g.s; o_r = g.r; o_x = gam_old == 0.0 ? c.vx[j0] : c.va[j0]; o_m = g.m;
   }
-  if (cont) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->run = stalled;
-    if (!stalled) return;
-  } else if (!bench && (!run || done)) return;
+  if (!bench && (!run || done || ((flags & 8) && stalled))) return;   // pre pass: skipped when this graph continues a solve
   LDS_DECL(1);
   double sums[3];
   bool first = false;
@@ -680,25 +551,12 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->tol2 = tol2; st->gam[1] = 0.0; st->alp[1] = 0.0; }
   } else {
-    const double rr = sums[0], gam = sums[1], del = sums[2];
-    const bool fresh = gam_old == 0.0;   // the pre pass zeroes gam[1]: first update of this solve
-    first = fresh;
-    if (first) { beta = 0.0; alpha = gam / del; }
-    else {
-      beta = gam / gam_old;
-      const double den = del - beta * gam / alp_old;
-      // The two-term recurrence for alpha loses positivity at the rounding floor of an
-      // ill-conditioned system although u'Ku > 0: restart the directions from u (p = u, s = w)
-      // instead of giving the solve up.
-      if (!(den > 0.0) && del > 0.0) { first = true; beta = 0.0; alpha = gam / del; }
-      else alpha = gam / den;
-    }
-    if (bench) { beta = 0.5; alpha = 1e-3; }
-    const bool conv = rr <= tol2;
-    const bool bad = !(alpha > 0.0) || !(del > 0.0);      // breakdown / negative curvature
-    const bool giveup = iters_prev >= prm.pcg_max_iter || neg || bad;
-    if (!bench && (conv || giveup)) {
-      if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = conv ? 1 : 2; if (bad && !conv) st->neg_curv = 1; }
+    const double gam = sums[1];
+    const bool fresh = gam_old == 0.0;
+    const CgStep cs = cg_step(sums[0], gam, sums[2], gam_old, alp_old, tol2, iters_prev, neg, prm, bench);
+    first = cs.first; alpha = cs.alpha; beta = cs.beta;
+    if (cs.stop) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = cs.conv ? 1 : 2; if (cs.bad && !cs.conv) st->neg_curv = 1; }
       return;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -815,16 +673,14 @@ __global__ void __launch_bounds__(TB) k_huge_reduce(Ctx c, int flags) {
 // needs ~190 registers; the plain instantiation stays lean for the sparse stream path).
 template <bool DENSE>
 __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
-  if (flags & 64) return;                                                            // timing probe: empty kernel
   State *st = c.st;
   const bool bench = flags & 4;
   if (!bench && it > c.prm->k_expect && (!st->run || st->done)) return;
-  const int run = st->run, done = st->done;
+  const int run = st->run, done = st->done, skip_pre = it < 0 && st->stalled;
   const double sigma = c.prm->sigma;
   const bool has_blk = (int)blockIdx.x < c.Mk.nstream;
   RowBlk b = {0, 0, 0, 0};
-  if (flags & 128) { b.r0 = blockIdx.x * 32; b.r1 = b.r0 + 32; b.k0 = blockIdx.x * 1000; b.k1 = b.k0 + 1000; }   // timing probe: descriptor known without a load
-  else if (has_blk) b = c.Mk.blk[blockIdx.x];
+  if (has_blk) b = c.Mk.blk[blockIdx.x];
   const int cnt = b.k1 - b.k0;
   const bool small = has_blk;
   double ev[EPT];
@@ -850,8 +706,7 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
       if (k < cnt) ev[e] = ev[e] * c.ut[ecol[e]];
     }
   }
-  if (!bench && (!run || done)) return;
-  if (flags & 16) { if (ev[0] == 12345.678 && run == 77) c.kp[0] = ev[1]; return; }   // timing probe: launch + prefetch only
+  if (!bench && (!run || done || skip_pre)) return;
   LDS_DECL(1);
   double pg = 0, pd = 0, prr = 0;
   for (int bi = blockIdx.x; bi < c.Mk.nstream; bi += gridDim.x) {
@@ -866,7 +721,6 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
       int a0, a1;
       if (bi == (int)blockIdx.x && j == b.r0 + rg) { a0 = rp0; a1 = rp1; }
       else { a0 = c.Mk.rowptr[j]; a1 = c.Mk.rowptr[j + 1]; }
-      if (flags & 128) { a0 = b.k0 + (j - b.r0) * 31; a1 = a0 + 31; }
       const double acc = row_sum_par(lprod, a0 - b.k0, a1 - b.k0, rlane, RL);
       if (rlane == 0) {
         const bool first = bi == (int)blockIdx.x && j == b.r0 + rg;
@@ -901,7 +755,6 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
     }
     __syncthreads();
   }
-  if (flags & 32) { if (pg == 12345.678) c.kp[0] = pd + prr; return; }                // timing probe: no block reductions
   block_sum3(pg, pd, prr, red);
   if (threadIdx.x == 0) { c.part_gam[blockIdx.x] = pg; c.part_del[blockIdx.x] = pd; c.part_rr[blockIdx.x] = prr; }
 }
@@ -910,6 +763,10 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
 // each); the consumer adds the partials in a fixed order.  Launched only when A has huge rows.
 __global__ void __launch_bounds__(TB) k_huge_dot(Ctx c, const double *x, int always) {
   if (!always && !c.st->run) return;
+  if (!x) {   // x~ as k_admm_finalize will see it (the start vector when no PCG update ran)
+    const State *st = c.st;
+    x = (c.vx != c.va && st->iters[0] == 0 && st->iters[1] == 0) ? c.vx : c.va;
+  }
   __shared__ double red[16];
   for (int bi = c.A.nwave; bi < c.A.nblk; ++bi) {
     const RowBlk hb = c.A.blk[bi];
@@ -942,8 +799,7 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
   LDS_DECL(1);
   const Params prm = *c.prm;
   double rr[1];
-  if (c.big) rr[0] = c.redout[0];
-  else reduce_parts<1>(c.part_rr, nullptr, nullptr, c.gridM, red, rr);
+  reduce_parts<1>(c.fin_rr, nullptr, nullptr, c.fin_cnt, red, rr);
   const int iters = st->iters[0] > st->iters[1] ? st->iters[0] : st->iters[1];
   const bool conv = st->done == 1 || rr[0] <= st->tol2;
   const bool force = st->done == 2 || iters >= prm.pcg_max_iter || st->neg_curv;
@@ -967,24 +823,28 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
   const int hist = st->hist_r;
   const double th = (hist < prm.ex_h0 ? 0.0 : (hist < prm.ex_h1 ? 0.5 : 1.0)) * prm.ex_theta;
   const bool ex = c.vx != c.va;
+  // the start vector itself passed the stop test (no PCG update ran): x~ is the start vector
+  const bool from_start = ex && iters == 0;
+  const double *xts = from_start ? c.vx : c.va;
   double *x = c.xy, *y = c.xy + c.n;
   for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
-    const double xo = x[j], xt = c.va[j];
+    const double xo = x[j], xt = xts[j];
     const double xn = alpha * xt + oma * xo;
     c.dxy[j] = xn - xo;
     x[j] = xn;
     if (ex) { c.vx[j] = xt + th * (xt - c.vold[j]); c.vold[j] = xt; }
+    if (from_start) c.va[j] = xt;
   }
   for (int bi = blockIdx.x; bi < c.A.nblk; bi += gridDim.x) {
     const RowBlk b = c.A.blk[bi];
     const bool longrow = IS_LONG(b);
     if (!longrow) {
-      stage_products<1>(c.A, b, c.va, nullptr, lprod, nullptr);
+      stage_products<1>(c.A, b, xts, nullptr, lprod, nullptr);
       __syncthreads();
     }
     for (int i = b.r0 + (longrow ? 0 : threadIdx.x); i < b.r1; i += (longrow ? 1 : TB)) {
       double zt;
-      if (longrow) zt = bi >= c.A.nwave ? huge_row_sum(c, bi, red) : long_row_dot(c.A, b.k0, b.k1, c.va, red);
+      if (longrow) zt = bi >= c.A.nwave ? huge_row_sum(c, bi, red) : long_row_dot(c.A, b.k0, b.k1, xts, red);
       else zt = row_sum(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0);
       if (!longrow || threadIdx.x == 0) {
         const double rho = c.rho[i], rinv = c.rhoinv[i], yo = y[i], zo = c.z[i];
@@ -1368,7 +1228,6 @@ struct hipeng {
   std::vector<void *> allocs;
   std::map<int, hipGraphExec_t> graphs, cgraphs;
   int K = 8;
-  int variant = 1;
   bool split = false;     // large A: vector update and operator apply as two launches (plain 8-byte gathers)
   int rlA = 8, rlM = 8;   // lanes per row segment in the PCG kernels
   bool calibrated = false;
@@ -1667,13 +1526,9 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
     if (repack_dense(e)) return HIPENG_ERR_HIP;
   }
   {
-    const char *v = getenv("OSQP_AMD_PCG_VARIANT");
-    e->variant = v ? atoi(v) : 1;          // 1 = Chronopoulos-Gear (2 kernels / iteration), 0 = classic (3)
     if (const char *t = getenv("OSQP_AMD_TRACE")) e->trace = std::max(1, atoi(t));
   }
-  c.big = 0;   // experimental (OSQP_AMD_BIG=1): measured slower than the capped grid on config 3
-  if (const char *bg = getenv("OSQP_AMD_BIG")) c.big = (atoi(bg) != 0 && e->variant == 1) ? 1 : 0;
-  const int cap = c.big ? BIG_GRID : MAX_PARTS;
+  const int cap = MAX_PARTS;
   c.gridM = std::min(cap, std::max(1, c.M.nblk));
   c.gridA = std::min(cap, std::max(std::max(1, c.A.nblk), std::min(elem_grid(n), 256)));
 #define DA(field, cnt) if (dev_alloc(e, &c.field, (size_t)(cnt))) return HIPENG_ERR_HIP
@@ -1688,13 +1543,11 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   DA(part_rz, np); DA(part_rr, np); DA(part_bb, np); DA(part_pkp, np);
   DA(part_s0, np); DA(part_s1, np); DA(part_s2, np); DA(part_gam, np); DA(part_del, np);
   DA(scal, SC_COUNT * 16);
-  DA(redout, 8);
   DA(part_h, (size_t)std::max(1, c.A.nblk - c.A.nwave) * c.gridA);
   DA(st, 1);
 #undef DA
   {
-    if (e->variant == 1) { c.init_r = &c.g4[n].r; c.init_stride = 4; c.init_z = c.ut; }
-    else { c.init_r = c.r; c.init_stride = 1; c.init_z = c.zz; }
+    c.init_r = &c.g4[n].r; c.init_stride = 4; c.init_z = c.ut;
   }
   if (dev_alloc(e, &e->d_prm, 1)) return HIPENG_ERR_HIP;
   c.prm = e->d_prm;
@@ -1705,13 +1558,13 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   e->prm.ex_theta = 1.0; e->prm.ex_h0 = 5; e->prm.ex_h1 = 12;
   if (const char *x = getenv("OSQP_AMD_EXTRAP_SCHED")) sscanf(x, "%d,%d", &e->prm.ex_h0, &e->prm.ex_h1);
   if (const char *x = getenv("OSQP_AMD_EXTRAP")) e->prm.ex_theta = atof(x);
-  if (e->variant != 1 || e->prm.ex_theta == 0.0) { e->prm.ex_theta = 0.0; c.vx = c.va; }   // classic variant: plain warm start
+  if (e->prm.ex_theta == 0.0) c.vx = c.va;   // plain warm start
   e->ex_theta0 = e->prm.ex_theta;
   if (prm->pcg_eps_rel < 1e-10) e->prm.ex_theta = 0.0;
   if (push_params(e)) return HIPENG_ERR_HIP;
   if (upload_vec(e, c.q, q, n) || upload_vec(e, c.l, l, m) || upload_vec(e, c.u, u, m) ||
       upload_vec(e, c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
-  e->stats.kernels_per_pcg_iter = e->variant == 1 ? 2 : 3;
+  e->stats.kernels_per_pcg_iter = 2;
   *out = e;
   if (rho_vec) { int rc = hipeng_upload_rho(e, rho_vec); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1964,20 +1817,12 @@ static void launch_cg_A(hipeng *e, int it, int flags) {
 static void launch_cg_B(hipeng *e, int it, int flags) {
   if (e->c.dP.nblk) hipLaunchKernelGGL(k_cg_B<true>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
   else hipLaunchKernelGGL(k_cg_B<false>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
-  if (e->c.big) hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(1024), 0, e->stream, e->c);
 }
 
 static void launch_pcg_iter(hipeng *e, int it, int flags) {
-  const Ctx &c = e->c;
-  if (e->variant == 1) {
-    if (e->split) { launch_cg_A(e, it, (flags & ~1) | 16); launch_cg_A(e, it, (flags & 4) | 32); }
-    else launch_cg_A(e, it, flags & ~1);
-    launch_cg_B(e, it, flags & 4);
-    return;
-  }
-  hipLaunchKernelGGL(k_pcg_Ap, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, flags);
-  hipLaunchKernelGGL(k_pcg_Kp, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags & 4);
-  hipLaunchKernelGGL(k_pcg_update, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, flags & 4);
+  if (e->split) { launch_cg_A(e, it, (flags & ~1) | 16); launch_cg_A(e, it, (flags & 4) | 32); }
+  else launch_cg_A(e, it, flags & ~1);
+  launch_cg_B(e, it, flags & 4);
 }
 
 static int get_graph(hipeng *e, int K, bool cont, hipGraphExec_t *out) {
@@ -1990,18 +1835,15 @@ static int get_graph(hipeng *e, int K, bool cont, hipGraphExec_t *out) {
   HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
   if (!cont) {
     launch_init(e);
-    if (e->c.big) hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(1024), 0, e->stream, e->c);
-    if (e->variant == 1) {   // operator apply on u0 (+ first convergence test), then w0 and the first dots
-      launch_cg_A(e, -1, 8);
-      launch_cg_B(e, -1, 0);
-    }
+    launch_cg_A(e, -1, 8);   // operator apply on u0 (+ first convergence test), then w0 and the first dots
+    launch_cg_B(e, -1, 0);
     for (int it = 0; it < K; it++) launch_pcg_iter(e, it, it == 0 ? 1 : 0);
   } else {
     // resumes at an even iteration index (K is always even): parity of the
     // ping-pong buffers / scalars is preserved
     for (int it = 0; it < K; it++) launch_pcg_iter(e, it + 2, it == 0 ? 2 : 0);
   }
-  if (e->c.A.nblk > e->c.A.nwave) hipLaunchKernelGGL(k_huge_dot, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, (const double *)e->c.va, 0);
+  if (e->c.A.nblk > e->c.A.nwave) hipLaunchKernelGGL(k_huge_dot, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, (const double *)nullptr, 0);
   hipLaunchKernelGGL(k_admm_finalize, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c);
   HIPCHK(hipStreamEndCapture(e->stream, &g));
   TR2(e, "get_graph: captured, instantiate");
@@ -2112,7 +1954,7 @@ extern "C" int hipeng_reset_stats(hipeng *e) {
   HIPCHK(hipMemcpyAsync(e->c.st, &s, sizeof(State), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->stats = hipeng_stats{};
-  e->stats.kernels_per_pcg_iter = e->variant == 1 ? 2 : 3;
+  e->stats.kernels_per_pcg_iter = 2;
   e->calibrated = false;
   e->K = 8;
   return 0;
@@ -2233,21 +2075,15 @@ extern "C" int hipeng_spmv(hipeng *e, int which, const c_float *x, c_float *y) {
 }
 
 extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) {
-  const int dbg = (which >> 8) & 0xff;
-  which &= 0xff;
   if (!e || !usec || reps <= 0 || which < 0 || which > 5) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   const Ctx &c = e->c;
   auto one = [&](int it) {
     if (which == 5) { launch_init(e); return; }   // first kernel of an ADMM iteration
-    if (e->variant == 1) {
-      if (which == 0) launch_cg_A(e, it, 4);
-      else if (which == 3) launch_cg_A(e, it, 4 | 16);
-      else if (which == 4) launch_cg_A(e, it, 4 | 32);
-      else launch_cg_B(e, it, 4 | dbg);
-    } else if (which == 0) hipLaunchKernelGGL(k_pcg_Ap, dim3(c.gridA), dim3(TB), 0, e->stream, c, it, 4);
-    else if (which == 1) hipLaunchKernelGGL(k_pcg_Kp, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, 4);
-    else hipLaunchKernelGGL(k_pcg_update, dim3(c.gridM), dim3(TB), 0, e->stream, c, it, 4);
+    if (which == 0) launch_cg_A(e, it, 4);
+    else if (which == 3) launch_cg_A(e, it, 4 | 16);
+    else if (which == 4) launch_cg_A(e, it, 4 | 32);
+    else launch_cg_B(e, it, 4);
   };
   // the launches are captured into one graph so the measurement is not bound by
   // the host's eager launch rate (~3-4 us per launch)
@@ -2271,27 +2107,21 @@ extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) 
 }
 
 // 1 if the vector update and the operator apply of k_cg_A run as two launches (A dominated by long rows)
-extern "C" int hipeng_is_split(hipeng *e) { return e && e->split && e->variant == 1 ? 1 : 0; }
+extern "C" int hipeng_is_split(hipeng *e) { return e && e->split ? 1 : 0; }
 
 extern "C" int hipeng_kernel_bytes(hipeng *e, int which, double *bytes) {
   if (!e || !bytes) return HIPENG_ERR_ARG;
   const double n = e->n, m = e->m;
-  const double nnzA = (double)e->A.val.size(), nnzM = (double)e->M.val.size();
+  const double nnzA = (double)e->A.val.size();
   const double nnzPtriu = (double)e->P_toM_up.size();
   // device layout: fp64 values + int32 indices (12 B per stored entry), one
   // int32 row pointer per row, fp64 vectors; gathers counted once per vector
-  if (e->variant == 1) {
-    // k_cg_A: A stream; u,w,p,s,r,Minv,x read + p,s,r,x,u written (12n); rho read, t written (2m)
-    if (which == 0)      *bytes = nnzA * 12 + (m + 1) * 4 + 8 * (12 * n + 2 * m);
-    // k_cg_B: [P|A'] stream; [u|t] and r read, w written.  P is counted as its stored upper
-    // triangle (each stored entry serves both triangles) although the fused row
-    // matrix M holds both, so the figure does not reward the expanded layout.
-    else if (which == 1) *bytes = (nnzA + nnzPtriu) * 12 + (n + 1) * 4 + 8 * ((n + m) + 2 * n);
-    else                 *bytes = 0;
-    return 0;
-  }
-  if (which == 0)       *bytes = nnzA * 12 + (m + 1) * 4 + 8 * (3 * n + 2 * m);   // zz,p_old -> p_new ; rho -> t
-  else if (which == 1)  *bytes = nnzM * 12 + (n + 1) * 4 + 8 * ((n + m) + n);     // [p|t] -> Kp
-  else                  *bytes = 8 * (7 * n);                                     // x~,r,Kp,p,Minv -> x~,r,zz
+  // k_cg_A: A stream; u,w,p,s,r,Minv,x read + p,s,r,x,u written (12n); rho read, t written (2m)
+  if (which == 0)      *bytes = nnzA * 12 + (m + 1) * 4 + 8 * (12 * n + 2 * m);
+  // k_cg_B: [P|A'] stream; [u|t] and r read, w written.  P is counted as its stored upper
+  // triangle (each stored entry serves both triangles) although the fused row
+  // matrix M holds both, so the figure does not reward the expanded layout.
+  else if (which == 1) *bytes = (nnzA + nnzPtriu) * 12 + (n + 1) * 4 + 8 * ((n + m) + 2 * n);
+  else                 *bytes = 0;
   return 0;
 }

@@ -8,6 +8,9 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-prof}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+# the same interceptor fault also shows without packet capture once a long graph's packets straddle the ring end (config 3,
+# --pmc pass): a ring large enough for the whole probe never wraps
+export ROC_AQL_QUEUE_SIZE=${ROC_AQL_QUEUE_SIZE:-524288}
 run() {
   local name=$1; shift
   timeout -k 10 900 "$@" > $O/$name.log 2>&1
@@ -15,8 +18,8 @@ run() {
   echo "$name rc=$rc" | tee -a $O/rc.txt
   if [ $rc -ne 0 ]; then tail -5 $O/$name.log; echo "stopping" | tee -a $O/rc.txt; exit 1; fi
 }
-for cfg in portfolio lasso; do
-  if [ $cfg = lasso ]; then export PROBE_MAX_ITER=${LASSO_MAX_ITER:-300}; id=config3; else unset PROBE_MAX_ITER; id=config5; fi
+for cfg in ${CONFIGS:-portfolio lasso}; do
+  if [ $cfg = lasso ]; then export PROBE_MAX_ITER=${LASSO_MAX_ITER:-200}; id=config3; else unset PROBE_MAX_ITER; id=config5; fi
   run ${id}_trace rocprofv3 --kernel-trace --stats --output-format csv -d $O/${id}_trace -- python3 $R/tools/c5probe.py $cfg
   run ${id}_fetch rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${id}_fetch -- python3 $R/tools/c5probe.py $cfg
   run ${id}_write rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${id}_write -- python3 $R/tools/c5probe.py $cfg

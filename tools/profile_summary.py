@@ -40,9 +40,10 @@ def main():
     tr, fe, wr, outp = sys.argv[1:5]
     dur, fetch, write = durations(tr), counters(fe, "FETCH_SIZE"), counters(wr, "WRITE_SIZE")
     res = {"note": "rocprofv3 on MI355X; separate passes: --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE. "
-                   "FETCH/WRITE in KB as reported (no gfx950 x2 correction: loads are 4/8 B per lane, outside the calibrated "
-                   "16 B/lane pattern). Launch counts include early-exit launches of converged PCG iterations; "
-                   "FETCH/WRITE medians are over active launches (those that moved more than 1 KB).",
+                   "FETCH/WRITE in KB as reported by the counters. Calibration (profiles/r02_fetch_calibration.json): FETCH_SIZE "
+                   "reports 1/2 of the bytes of a coalesced streaming read at 4, 8 and 16 B per lane, WRITE_SIZE is exact, so "
+                   "HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE ('traffic_bytes_corrected'). Launch counts include "
+                   "early-exit launches of converged PCG iterations; FETCH/WRITE medians are over active launches (> 1 KB moved).",
            "kernels": {}}
     for k in sorted(set(dur) | set(fetch) | set(write)):
         e = {}
@@ -53,6 +54,8 @@ def main():
         if dur.get(k):
             v = dur[k]
             e["duration_ns"] = {"median": statistics.median(v), "p10": pct(v, 0.1), "p90": pct(v, 0.9), "mean": sum(v) / len(v), "launches": len(v)}
+        if "FETCH_SIZE_KB" in e and "WRITE_SIZE_KB" in e:
+            e["traffic_bytes_corrected"] = round(1024.0 * (2.0 * e["FETCH_SIZE_KB"]["median"] + e["WRITE_SIZE_KB"]["median"]))
         res["kernels"][k] = e
     json.dump(res, open(outp, "w"), indent=1)
     for k, e in res["kernels"].items():
