@@ -33,6 +33,8 @@ typedef struct {
   c_float pcg_eps_rel;  /* PCG stops at ||r||_2 <= max(eps_rel*||b||_2, eps_abs) */
   c_float pcg_eps_abs;
   c_int   pcg_max_iter; /* hard cap per linear solve                        */
+  c_int   no_restart;   /* 1: any loss of positivity in the CG recurrence counts as negative
+                           curvature (setup-time convexity probe); 0: restart at the rounding floor */
 } hipeng_params;
 
 /* Scalars produced by one residual evaluation (replaces the reductions inside

@@ -370,13 +370,15 @@ __device__ __forceinline__ double dense_block_mv(const DenseP &dP, const DenseBl
 // closer to x~_{k+1} than x~_k is), preconditioned residual and the three start-up dot
 // products.  One dual-stream pass over M.
 template <bool DENSE>
-__global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
+__global__ void __launch_bounds__(TB) k_pcg_init(Ctx c, int bench) {
   State *st = c.st;
   // A solve that ran out of unrolled PCG iterations (`stalled`, raised by k_admm_finalize) is continued by
   // this graph launch: no new right-hand side, the iteration kernels below pick the recurrences up where they
   // stopped (K is even, so the parity of every ping-pong buffer is preserved).
-  if (st->stalled) return;
-  if (st->admm_done >= st->admm_target) { if (blockIdx.x == 0 && threadIdx.x == 0) st->run = 0; return; }
+  if (!bench) {
+    if (st->stalled) return;
+    if (st->admm_done >= st->admm_target) { if (blockIdx.x == 0 && threadIdx.x == 0) st->run = 0; return; }
+  }
   LDS_DECL(2);
   const Params prm = *c.prm;
   double prz = 0, prr = 0, pbb = 0;
@@ -408,17 +410,19 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c) {
       stage_products<2>(Mm, b, c.vx, c.vb, lprod, lprod + MAX_CHUNK);
       __syncthreads();
     }
-    for (int j = b.r0 + (longrow ? 0 : threadIdx.x); j < b.r1; j += (longrow ? 1 : TB)) {
+    // the summation order is free here (PCG-internal): several lanes per row
+    const int RL = longrow ? 1 : lanes_for(b.r1 - b.r0), rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
+    for (int j = b.r0 + (longrow ? 0 : rg); j < b.r1; j += (longrow ? 1 : TB / RL)) {
       double sA, sB;
       if (longrow) {
         sA = long_row_dot(Mm, b.k0, b.k1, c.vx, red);
         sB = long_row_dot(Mm, b.k0, b.k1, c.vb, red);
       } else {
         const int a0 = Mm.rowptr[j] - b.k0, a1 = Mm.rowptr[j + 1] - b.k0;
-        sA = row_sum(lprod, a0, a1);
-        sB = row_sum(lprod + MAX_CHUNK, a0, a1);
+        sA = row_sum_par(lprod, a0, a1, rlane, RL);
+        sB = row_sum_par(lprod + MAX_CHUNK, a0, a1, rlane, RL);
       }
-      if (!longrow || threadIdx.x == 0) {
+      if (longrow ? threadIdx.x == 0 : rlane == 0) {
         const double base = prm.use_cvec ? c.cvec[j] : (prm.sigma * c.xy[j] - c.q[j]);
         const double bj = base + sB;
         const double rj = bj - prm.sigma * c.vx[j] - sA;
@@ -842,11 +846,12 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
       stage_products<1>(c.A, b, xts, nullptr, lprod, nullptr);
       __syncthreads();
     }
-    for (int i = b.r0 + (longrow ? 0 : threadIdx.x); i < b.r1; i += (longrow ? 1 : TB)) {
+    const int RL = longrow ? 1 : lanes_for(b.r1 - b.r0), rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
+    for (int i = b.r0 + (longrow ? 0 : rg); i < b.r1; i += (longrow ? 1 : TB / RL)) {
       double zt;
       if (longrow) zt = bi >= c.A.nwave ? huge_row_sum(c, bi, red) : long_row_dot(c.A, b.k0, b.k1, xts, red);
-      else zt = row_sum(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0);
-      if (!longrow || threadIdx.x == 0) {
+      else zt = row_sum_par(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0, rlane, RL);
+      if (longrow ? threadIdx.x == 0 : rlane == 0) {
         const double rho = c.rho[i], rinv = c.rhoinv[i], yo = y[i], zo = c.z[i];
         double v = alpha * zt + oma * zo + rinv * yo;
         v = fmax(v, c.l[i]);
@@ -1226,14 +1231,16 @@ struct hipeng {
   Params prm{};
   Params *d_prm = nullptr;
   std::vector<void *> allocs;
-  std::map<int, hipGraphExec_t> graphs, cgraphs;
+  std::map<int, hipGraphExec_t> graphs;
   int K = 8;
   bool split = false;     // large A: vector update and operator apply as two launches (plain 8-byte gathers)
   int rlA = 8, rlM = 8;   // lanes per row segment in the PCG kernels
   bool calibrated = false;
   double ex_theta0 = 1.0;    // OSQP_AMD_EXTRAP (0 disables the extrapolated PCG start)
   bool start_dirty = true;   // [x~ | rho z~] was rewritten from outside the loop: PCG start history is void
-  int warm_windows = 0;   // windows since the last (re)calibration: bursts grow 1, 4, 8, then up to 64
+  long long admm_total = 0;            // host copy of State::admm_done
+  State *h_state = nullptr;            // pinned staging for the state read-back and the target upload
+  long long *h_target = nullptr;
   int trace = 0;            // OSQP_AMD_TRACE: 1 = one line per window, 2 = every HIP call of the run loop
   hipeng_stats stats{};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1253,7 +1260,7 @@ static int dev_alloc(hipeng *e, T **p, size_t count) {
 
 // Greedy row blocks: as many whole rows as fit `chunk` products (at least one
 // row; a single row may exceed MAX_CHUNK and then takes the long-row path).
-static void build_blocks(HostMat &H, int chunk, bool huge_ok, const std::vector<char> *skip = nullptr) {
+static void build_blocks(HostMat &H, int chunk, bool huge_ok, const std::vector<char> *skip = nullptr, int long_row = LONG_ROW) {
   // stream blocks first (runs of consecutive short rows, at most `chunk` products),
   // then one block per long row: the PCG kernels give each long row a wavefront
   H.blk.clear();
@@ -1262,12 +1269,12 @@ static void build_blocks(HostMat &H, int chunk, bool huge_ok, const std::vector<
   while (r < H.nrows) {
     if (skip && (*skip)[r]) { r++; continue; }     // rows served by another path (dense blocks of P)
     const int k0 = H.rowptr[r];
-    if (H.rowptr[r + 1] - k0 >= LONG_ROW) {
+    if (H.rowptr[r + 1] - k0 >= long_row) {
       ((huge_ok && H.rowptr[r + 1] - k0 >= HUGE_ROW) ? huges : longs).push_back({r, r + 1, k0, H.rowptr[r + 1]});
       r++; continue;
     }
     int r1 = r + 1;
-    while (r1 < H.nrows && !(skip && (*skip)[r1]) && H.rowptr[r1 + 1] - H.rowptr[r1] < LONG_ROW &&
+    while (r1 < H.nrows && !(skip && (*skip)[r1]) && H.rowptr[r1 + 1] - H.rowptr[r1] < long_row &&
            H.rowptr[r1 + 1] - k0 <= chunk && (r1 - r) < 8 * TB) r1++;
     H.blk.push_back({r, r1, k0, H.rowptr[r1]});
     r = r1;
@@ -1441,6 +1448,16 @@ static int repack_dense(hipeng *e) {
   return 0;
 }
 
+static int elem_grid(int cnt) {
+  int g = (cnt + TB - 1) / TB;
+  return std::max(1, std::min(g, MAX_PARTS));
+}
+
+// Everything derived from (P, A, rho, sigma): the Jacobi preconditioner.
+static void refresh_operator(hipeng *e) {
+  hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
+}
+
 // The PCG start vector history is void (cold/warm start from the host, new rho, new matrices):
 // start from [x~ | rho z~] as it stands and extrapolate again once a few iterations are on record.
 static int reset_start(hipeng *e) {
@@ -1461,11 +1478,6 @@ static int push_params(hipeng *e) {
   // the source is host-pageable and may be reused right away
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
-}
-
-static int elem_grid(int cnt) {
-  int g = (cnt + TB - 1) / TB;
-  return std::max(1, std::min(g, MAX_PARTS));
 }
 
 extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_float *q,
@@ -1547,7 +1559,9 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   DA(st, 1);
 #undef DA
   {
-    c.init_r = &c.g4[n].r; c.init_stride = 4; c.init_z = c.ut;
+    c.init_r = &c.g4[n].r; c.init_stride = 4; c.init_z = c.ut; c.fin_rr = c.part_rr; c.fin_cnt = c.gridM;
+    HIPCHK(hipHostMalloc((void **)&e->h_state, sizeof(State), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&e->h_target, sizeof(long long), hipHostMallocDefault));
   }
   if (dev_alloc(e, &e->d_prm, 1)) return HIPENG_ERR_HIP;
   c.prm = e->d_prm;
@@ -1555,7 +1569,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   e->prm.eps_rel = prm->pcg_eps_rel; e->prm.eps_abs = prm->pcg_eps_abs;
   e->prm.pcg_max_iter = (int)prm->pcg_max_iter; e->prm.cinv = 1.0;
   e->prm.use_cvec = 0; e->prm.has_scaling = 0; e->prm.k_expect = 1 << 30;
-  e->prm.ex_theta = 1.0; e->prm.ex_h0 = 5; e->prm.ex_h1 = 12;
+  e->prm.ex_theta = 1.0; e->prm.ex_h0 = 5; e->prm.ex_h1 = 12; e->prm.no_restart = 0;
   if (const char *x = getenv("OSQP_AMD_EXTRAP_SCHED")) sscanf(x, "%d,%d", &e->prm.ex_h0, &e->prm.ex_h1);
   if (const char *x = getenv("OSQP_AMD_EXTRAP")) e->prm.ex_theta = atof(x);
   if (e->prm.ex_theta == 0.0) c.vx = c.va;   // plain warm start
@@ -1576,10 +1590,11 @@ extern "C" void hipeng_destroy(hipeng *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.second);
-  for (auto &g : e->cgraphs) (void)hipGraphExecDestroy(g.second);
   for (void *p : e->allocs) (void)hipFree(p);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->h_state) (void)hipHostFree(e->h_state);
+  if (e->h_target) (void)hipHostFree(e->h_target);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1596,14 +1611,14 @@ extern "C" int hipeng_set_params(hipeng *e, const hipeng_params *prm) {
   const bool sigma_changed = prm->sigma != e->prm.sigma;
   e->prm.sigma = prm->sigma; e->prm.alpha = prm->alpha;
   e->prm.eps_rel = prm->pcg_eps_rel; e->prm.eps_abs = prm->pcg_eps_abs;
-  e->prm.pcg_max_iter = (int)prm->pcg_max_iter;
+  e->prm.pcg_max_iter = (int)prm->pcg_max_iter; e->prm.no_restart = prm->no_restart ? 1 : 0;
   // Extrapolated start vectors pay while PCG does real work.  When the caller asks for more
   // than the default accuracy (tight eps_abs/eps_rel tighten pcg_eps_rel, see osqp_solve) every
   // digit of the solve counts and the residual-based stop from a closer start leaves a
   // slightly larger error: plain warm start there.
   e->prm.ex_theta = prm->pcg_eps_rel >= 1e-10 ? e->ex_theta0 : 0.0;
   if (push_params(e)) return HIPENG_ERR_HIP;
-  if (sigma_changed) hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
+  if (sigma_changed) refresh_operator(e);
   return 0;
 }
 
@@ -1698,7 +1713,7 @@ extern "C" int hipeng_upload_rho(hipeng *e, const c_float *rho_vec) {
     if (upload_vec(e, e->c.rho, rho_vec, e->m)) return HIPENG_ERR_HIP;
     hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
   }
-  hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
+  refresh_operator(e);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));
   e->calibrated = false;   // the PCG iteration count usually jumps after a rho change
@@ -1727,7 +1742,7 @@ extern "C" int hipeng_upload_matrices(hipeng *e, const csc *P, const csc *A) {
       upload_vec(e, e->A.d_val, e->A.val.data(), e->A.val.size()) ||
       upload_vec(e, e->c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
   if (repack_dense(e)) return HIPENG_ERR_HIP;
-  hipLaunchKernelGGL(k_precond, dim3(elem_grid(n)), dim3(TB), 0, e->stream, e->c);
+  refresh_operator(e);
   // z~ = A x~ for the new A so that the PCG warm start stays consistent
   if (e->m > 0) {
     hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, e->c.va, e->c.zt, 0);
@@ -1744,7 +1759,7 @@ extern "C" int hipeng_matrices_changed(hipeng *e) {
   if (!e) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   if (repack_dense(e)) return HIPENG_ERR_HIP;
-  hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
+  refresh_operator(e);
   if (e->m > 0) {
     hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, e->c.va, e->c.zt, 0);
     hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
@@ -1805,10 +1820,11 @@ extern "C" int hipeng_set_z(hipeng *e, const c_float *z) {
 
 // ---- graphs ---------------------------------------------------------------
 #define TR2(e, ...) do { if ((e)->trace >= 2) { fprintf(stderr, "[osqp_amd:t2] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
-static void launch_init(hipeng *e) {
-  if (e->c.dP.nblk) hipLaunchKernelGGL(k_pcg_init<true>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c);
-  else hipLaunchKernelGGL(k_pcg_init<false>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c);
+static void launch_init(hipeng *e, int bench = 0) {
+  if (e->c.dP.nblk) hipLaunchKernelGGL(k_pcg_init<true>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, bench);
+  else hipLaunchKernelGGL(k_pcg_init<false>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, bench);
 }
+
 static void launch_cg_A(hipeng *e, int it, int flags) {
   hipLaunchKernelGGL(k_cg_A, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, it, flags);
   const int nhuge = e->c.A.nblk - e->c.A.nwave;
@@ -1820,44 +1836,45 @@ static void launch_cg_B(hipeng *e, int it, int flags) {
 }
 
 static void launch_pcg_iter(hipeng *e, int it, int flags) {
-  if (e->split) { launch_cg_A(e, it, (flags & ~1) | 16); launch_cg_A(e, it, (flags & 4) | 32); }
-  else launch_cg_A(e, it, flags & ~1);
+  if (e->split) { launch_cg_A(e, it, (flags & 4) | 16); launch_cg_A(e, it, (flags & 4) | 32); }
+  else launch_cg_A(e, it, flags & 4);
   launch_cg_B(e, it, flags & 4);
 }
 
-static int get_graph(hipeng *e, int K, bool cont, hipGraphExec_t *out) {
-  auto &cache = cont ? e->cgraphs : e->graphs;
-  auto f = cache.find(K);
-  if (f != cache.end()) { *out = f->second; return 0; }
+// One ADMM iteration as a graph: k_pcg_init, the operator on u0 ("pre" pass), K unrolled PCG
+// iterations, k_admm_finalize.  If K was too small, k_admm_finalize raises `stalled` and the NEXT
+// launch of the same graph continues the solve (its init and pre pass return at once).
+// R such segments back to back form one graph (a graph launch has a fixed cost of its own on the GPU
+// timeline); a segment whose predecessor stalled continues it, segments beyond admm_target return at once.
+static int get_graph(hipeng *e, int K, int R, hipGraphExec_t *out) {
+  const int key = K * 64 + R;
+  auto f = e->graphs.find(key);
+  if (f != e->graphs.end()) { *out = f->second; return 0; }
   hipGraph_t g = nullptr;
   hipGraphExec_t ge = nullptr;
-  TR2(e, "get_graph K=%d cont=%d: begin capture", K, (int)cont);
+  TR2(e, "get_graph K=%d R=%d: begin capture", K, R);
   HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-  if (!cont) {
+  for (int seg = 0; seg < R; seg++) {
     launch_init(e);
-    launch_cg_A(e, -1, 8);   // operator apply on u0 (+ first convergence test), then w0 and the first dots
-    launch_cg_B(e, -1, 0);
-    for (int it = 0; it < K; it++) launch_pcg_iter(e, it, it == 0 ? 1 : 0);
-  } else {
-    // resumes at an even iteration index (K is always even): parity of the
-    // ping-pong buffers / scalars is preserved
-    for (int it = 0; it < K; it++) launch_pcg_iter(e, it + 2, it == 0 ? 2 : 0);
+    launch_cg_A(e, -1, 8); launch_cg_B(e, -1, 0);   // operator apply on u0 (+ first convergence test), then w0 and the first dots
+    for (int it = 0; it < K; it++) launch_pcg_iter(e, it, 0);
+    if (e->c.A.nblk > e->c.A.nwave) hipLaunchKernelGGL(k_huge_dot, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, (const double *)nullptr, 0);
+    hipLaunchKernelGGL(k_admm_finalize, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c);
   }
-  if (e->c.A.nblk > e->c.A.nwave) hipLaunchKernelGGL(k_huge_dot, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, (const double *)nullptr, 0);
-  hipLaunchKernelGGL(k_admm_finalize, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c);
   HIPCHK(hipStreamEndCapture(e->stream, &g));
   TR2(e, "get_graph: captured, instantiate");
   HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   TR2(e, "get_graph: instantiated");
   HIPCHK(hipGraphDestroy(g));
-  cache[K] = ge;
+  e->graphs[key] = ge;
   *out = ge;
   return 0;
 }
 
 static int read_state(hipeng *e, State *s) {
-  HIPCHK(hipMemcpyAsync(s, e->c.st, sizeof(State), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_state, e->c.st, sizeof(State), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  *s = *e->h_state;
   return 0;
 }
 
@@ -1885,57 +1902,56 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
       }
     }
   }
-  TR2(e, "run_admm count=%lld: read_state", (long long)count);
-  // reset the per-call maximum
-  if (read_state(e, &s)) return HIPENG_ERR_HIP;
+  // admm_done only moves inside this function: the host keeps its own copy, so a call starts
+  // without a device round trip.  The device stops starting iterations at admm_target.
+  if (count == 0) return 0;
+  const long long start = e->admm_total, target = start + (long long)count;
+  *e->h_target = target;
+  HIPCHK(hipMemcpyAsync(&e->c.st->admm_target, e->h_target, sizeof(long long), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemsetAsync(&e->c.st->iters_max, 0, sizeof(int), e->stream));
   if (e->start_dirty) { if (reset_start(e)) return HIPENG_ERR_HIP; e->start_dirty = false; }
-  const long long start = s.admm_done;
   long long remaining = count;
   const int cap = std::max(2, e->prm.pcg_max_iter);
+  static const int khead = getenv("OSQP_AMD_KHEAD") ? atoi(getenv("OSQP_AMD_KHEAD")) : 1;   // unrolled iterations beyond the last window's maximum
   int guard = 0, call_max = 0;
+  s.admm_done = start; s.iters_last = 0; s.iters_total = 0; s.forced = 0; s.neg_curv_seen = 0;
+  static const int segs = getenv("OSQP_AMD_GRAPH_SEGS") ? std::max(1, std::min(32, atoi(getenv("OSQP_AMD_GRAPH_SEGS")))) : 5;
   while (remaining > 0) {
-    hipGraphExec_t ge;
-    if (get_graph(e, e->K, false, &ge)) return HIPENG_ERR_HIP;
-    if (!e->calibrated) { e->warm_windows = 0; e->calibrated = true; }
-    static const int ramp[] = {1, 4, 8};
-    const long long burst = std::min<long long>(remaining, e->warm_windows < 3 ? ramp[e->warm_windows] : 64);
-    e->warm_windows++;
+    // after a reset (cold start, new rho, new matrices) the PCG iteration count jumps: two
+    // iterations to see where it lands, then whole windows
+    const long long burst = std::min<long long>(remaining, e->calibrated ? 128 : 2);
     TR2(e, "launch burst=%lld K=%d", burst, e->K);
-    for (long long i = 0; i < burst; i++) HIPCHK(hipGraphLaunch(ge, e->stream));
-    e->stats.graph_launches += (c_int)burst;
-    TR2(e, "burst enqueued, read_state");
+    // `burst` ADMM iterations = burst / segs graphs of `segs` segments + single-segment graphs for the rest
+    // (graphs with many nodes only when the unroll is short: keeps instantiation cheap for long PCG runs)
+    const int R = e->K <= 48 ? segs : 1;
+    hipGraphExec_t gR = nullptr, g1 = nullptr;
+    if (burst >= R && R > 1 && get_graph(e, e->K, R, &gR)) return HIPENG_ERR_HIP;
+    if ((!gR || burst % R) && get_graph(e, e->K, 1, &g1)) return HIPENG_ERR_HIP;
+    long long left = burst;
+    for (; gR && left >= R; left -= R) { HIPCHK(hipGraphLaunch(gR, e->stream)); e->stats.graph_launches += 1; }
+    for (; left > 0; left--) { HIPCHK(hipGraphLaunch(g1, e->stream)); e->stats.graph_launches += 1; }
     if (read_state(e, &s)) return HIPENG_ERR_HIP;
-    TR2(e, "state read: done=%lld stalled=%d", (long long)(s.admm_done - start), s.stalled);
-    while (s.stalled) {            // finish the stalled solve with more PCG iterations
-      hipGraphExec_t gc;
-      const int Kc = next_K(std::max(2 * e->K, 16), cap);
-      if (get_graph(e, Kc, true, &gc)) return HIPENG_ERR_HIP;
-      HIPCHK(hipGraphLaunch(gc, e->stream));
-      e->stats.graph_launches += 1;
-      if (read_state(e, &s)) return HIPENG_ERR_HIP;
-      if (e->trace) fprintf(stderr, "[osqp_amd]   stall: continue graph Kc=%d -> iters %d stalled=%d\n", Kc, std::max(s.iters[0], s.iters[1]), s.stalled);
-      e->K = next_K(std::max(e->K + 2, (int)(1.5 * std::max(s.iters[0], s.iters[1])) + 2), cap);
-      if (++guard > 100000) { fprintf(stderr, "osqp_amd: PCG continuation did not terminate\n"); return HIPENG_ERR_HIP; }
-    }
-    remaining = count - (s.admm_done - start);
+    const long long done_now = s.admm_done - start;
+    const bool stalls = count - done_now > remaining - burst;       // some launches were continuations
+    remaining = count - done_now;
     call_max = std::max(call_max, s.iters_max);
-    if (remaining > 0) {     // the next burst is sized from its predecessor alone: restart the device-side maximum
-      HIPCHK(hipMemsetAsync(&e->c.st->iters_max, 0, sizeof(int), e->stream));
+    const int in_flight = s.stalled ? std::max(s.iters[0], s.iters[1]) : 0;
+    if (e->trace) fprintf(stderr, "[osqp_amd] window: K=%d burst=%lld done=%lld iters_max=%d last=%d stalled=%d(%d) launches=%lld\n", e->K, burst, done_now, s.iters_max, s.iters_last, s.stalled, in_flight, (long long)e->stats.graph_launches);
+    // next unroll count: the last window's maximum (the last solve's count right after a reset,
+    // where the counts are still falling) plus a little head-room; a solve that needs more simply
+    // takes a second graph launch
+    int base = e->calibrated ? std::max(s.iters_max, in_flight) : std::max(s.iters_last, in_flight);
+    if (stalls && base <= e->K) base = e->K + 2;
+    e->K = next_K(std::max(2, base + khead), cap);
+    e->calibrated = true;
+    if (remaining > 0) HIPCHK(hipMemsetAsync(&e->c.st->iters_max, 0, sizeof(int), e->stream));
+    if (std::abs(e->prm.k_expect - base) > 1) {
+      e->prm.k_expect = base;
+      if (push_params(e)) return HIPENG_ERR_HIP;
     }
-    if (e->trace) fprintf(stderr, "[osqp_amd] window: K=%d burst=%lld done=%lld iters_max=%d last=%d launches=%lld\n", e->K, burst, (long long)(s.admm_done - start), s.iters_max, s.iters_last, (long long)e->stats.graph_launches);
-    // track the iteration count: shrink slowly, grow at once
-    static const int khead = getenv("OSQP_AMD_KHEAD") ? atoi(getenv("OSQP_AMD_KHEAD")) : 3;   // tuning experiments
-    const int want = s.iters_max + std::max(khead, s.iters_max / 6);   // head-room against drift between windows
-    const int Kn = next_K(want, cap);
-    e->K = Kn;
-    if (std::abs(e->prm.k_expect - s.iters_max) > 1) {
-      e->prm.k_expect = s.iters_max;
-      HIPCHK(hipMemcpyAsync(e->d_prm, &e->prm, sizeof(Params), hipMemcpyHostToDevice, e->stream));
-      HIPCHK(hipStreamSynchronize(e->stream));
-    }
-    if (++guard > 1000000) return HIPENG_ERR_HIP;
+    if (++guard > 1000000) { fprintf(stderr, "osqp_amd: the ADMM run loop did not terminate\n"); return HIPENG_ERR_HIP; }
   }
+  e->admm_total = s.admm_done;
   e->stats.admm_done = (c_int)(s.admm_done - start);
   e->stats.pcg_iters_total = (c_int)s.iters_total;
   e->stats.pcg_iters_last = s.iters_last;
@@ -2075,11 +2091,12 @@ extern "C" int hipeng_spmv(hipeng *e, int which, const c_float *x, c_float *y) {
 }
 
 extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) {
-  if (!e || !usec || reps <= 0 || which < 0 || which > 5) return HIPENG_ERR_ARG;
+  if (!e || !usec || reps <= 0 || which < 0 || which > 7) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
-  const Ctx &c = e->c;
   auto one = [&](int it) {
-    if (which == 5) { launch_init(e); return; }   // first kernel of an ADMM iteration
+    if (which == 5) { launch_init(e, 1); return; }   // first kernel of an ADMM iteration
+    if (which == 6) { launch_pcg_iter(e, it, 4); return; }   // one whole PCG iteration (all its launches, in loop order)
+    if (which == 7) { hipLaunchKernelGGL(k_fill, dim3(1), dim3(TB), 0, e->stream, e->c.cvec, 0.0, 0); return; }   // empty dependent launch
     if (which == 0) launch_cg_A(e, it, 4);
     else if (which == 3) launch_cg_A(e, it, 4 | 16);
     else if (which == 4) launch_cg_A(e, it, 4 | 32);

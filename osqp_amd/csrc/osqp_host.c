@@ -71,6 +71,7 @@ static void fill_params(hipeng_params *p, c_float sigma, c_float alpha, c_int n)
   p->sigma = sigma; p->alpha = alpha;
   p->pcg_eps_rel = g_opt.pcg_eps_rel; p->pcg_eps_abs = g_opt.pcg_eps_abs;
   p->pcg_max_iter = g_opt.pcg_max_iter > 0 ? g_opt.pcg_max_iter : HMAX(1000, 2 * n);
+  p->no_restart = 0;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -495,7 +496,7 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
   {
     c_int probe = HMIN(HMAX(2 * n, 8), 64);
     hipeng_params pp = prm;
-    pp.pcg_max_iter = probe;
+    pp.pcg_max_iter = probe; pp.no_restart = 1;
     c_float *rhs = (c_float *)malloc((size_t)(n + m + 1) * sizeof(c_float));
     unsigned long long lcg = 88172645463325252ULL;
     if (!rhs) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");

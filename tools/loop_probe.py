@@ -1,0 +1,24 @@
+"""Steady-state cost of the ADMM loop on config 2: long windows, no termination checks, no rho updates.
+usage: python tools/loop_probe.py [n m]"""
+import sys, os, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, osqp_amd
+from osqp_amd.problems import random_sparse_qp
+n, m = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (10000, 20000)
+pb = random_sparse_qp(n, m, seed=1)
+s = osqp_amd.OSQP().setup(**pb, eps_abs=1e-13, eps_rel=1e-13, max_iter=600, check_termination=300, adaptive_rho=0, warm_start=0)
+s.solve()
+st0 = s.stats()
+t0 = time.perf_counter(); r = s.solve(); dt = time.perf_counter() - t0
+st = s.stats()
+pcg = st["pcg_iters_total"] - st0["pcg_iters_total"]
+L = osqp_amd.lib()
+L.hipeng_time_kernel.restype = C.c_int; L.hipeng_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+us = [C.c_double() for _ in range(5)]
+for k, w in enumerate((0, 1, 5, 6, 7)):
+    L.hipeng_time_kernel(s.engine(), w, 200, C.byref(us[k]))
+print("iters %d in %.3f ms -> %.1f us per ADMM iteration; %.2f PCG iterations each; launches %d syncs %d" % (
+    r.info.iter, 1e3 * dt, 1e6 * dt / r.info.iter, pcg / r.info.iter, st["graph_launches"] - st0["graph_launches"], st["host_syncs"] - st0["host_syncs"]))
+print("kernel periods: A %.2f us, B %.2f us, init %.2f us -> PCG kernels alone %.1f us per ADMM iteration" % (
+    us[0].value, us[1].value, us[2].value, (pcg / r.info.iter + 1) * (us[0].value + us[1].value)))
+print("one PCG iteration in loop order (A then B): %.2f us; empty dependent launch: %.2f us" % (us[3].value, us[4].value))
