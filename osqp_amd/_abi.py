@@ -26,6 +26,8 @@ STATUS = {
 }
 OSQP_SOLVED = 1
 OSQP_SOLVED_INACCURATE = 2
+OSQP_PRIMAL_INFEASIBLE_INACCURATE = 3
+OSQP_DUAL_INFEASIBLE_INACCURATE = 4
 OSQP_MAX_ITER_REACHED = -2
 OSQP_PRIMAL_INFEASIBLE = -3
 OSQP_DUAL_INFEASIBLE = -4

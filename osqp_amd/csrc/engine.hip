@@ -2015,7 +2015,9 @@ extern "C" int hipeng_residuals(hipeng *e, hipeng_scalars *out) {
 extern "C" int hipeng_certificates(hipeng *e, c_float eps_dx, int unscaled, hipeng_scalars *io) {
   if (!e || !io) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipMemsetAsync(e->c.scal + SCI(SC_ATDY_U), 0, 5 * sizeof(double), e->stream));
+  // the five output slots (one 128-byte line each, SC_ATDY_U .. SC_ADX_VIOL) start from zero on every call:
+  // the exact and the approximate check of one iteration both come here
+  HIPCHK(hipMemsetAsync(e->c.scal + SCI(SC_ATDY_U), 0, (size_t)(SCI(SC_ADX_VIOL) - SCI(SC_ATDY_U) + 1) * sizeof(double), e->stream));
   hipLaunchKernelGGL(k_certificates, dim3(e->c.gridA + e->c.gridM), dim3(TB), 0, e->stream, e->c,
                      (double)eps_dx, unscaled);
   HIPCHK(hipGetLastError());

@@ -492,9 +492,11 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
    * positive pivots (qdldl_interface.c:93-99, OSQP_NONCVX_ERROR), i.e. a reduced matrix
    * P + sigma I + A' rho A that is not positive definite.  An iterative solver has no inertia;
    * the equivalent signal is negative curvature p'Kp <= 0 met by CG.  A short CG run on a
-   * fixed pseudo-random right-hand side is a best-effort version of that test. */
+   * fixed pseudo-random right-hand side is a best-effort version of that test (up to 300 iterations; it
+   * ends as soon as the solve converges, and during it ANY loss of positivity in the recurrence counts --
+   * no restart at the rounding floor, hipeng_params.no_restart). */
   {
-    c_int probe = HMIN(HMAX(2 * n, 8), 64);
+    c_int probe = HMIN(HMAX(2 * n, 8), 300);
     hipeng_params pp = prm;
     pp.pcg_max_iter = probe; pp.no_restart = 1;
     c_float *rhs = (c_float *)malloc((size_t)(n + m + 1) * sizeof(c_float));
@@ -707,7 +709,7 @@ c_int osqp_solve(OSQPWorkspace *w) {
   if (!w) { fprintf(stderr, "ERROR in osqp_solve: Workspace not initialized\n"); return OSQP_WORKSPACE_NOT_INIT_ERROR; }
   hip_pcg_solver *s = PCG(w);
   OSQPSettings *st = w->settings;
-  c_int exitflag = 0, iter = 0, can_check = 0, can_print = 0;
+  c_int exitflag = 0, iter = 0, can_check = 0, can_print = 0, timed_out = 0;
   const c_int with_obj = st->verbose;
 
   if (w->clear_update_time == 1) w->info->update_time = 0.0;
@@ -728,6 +730,11 @@ c_int osqp_solve(OSQPWorkspace *w) {
   {
     const c_float e = HMIN(st->eps_abs > 0 ? st->eps_abs : st->eps_rel, st->eps_rel > 0 ? st->eps_rel : st->eps_abs);
     if (e > 0) prm.pcg_eps_rel = HMAX(1e-13, HMIN(prm.pcg_eps_rel, 1e-6 * e));
+    /* Equality rows carry rho_eq = 1e3 rho (constants.h:70): ||b|| is then dominated by their terms and a stop
+     * relative to ||b|| leaves the rest of x~ 1e2..1e3 times less accurate (configs 3 and 5: x, y within 1e-4
+     * of the direct solve at 1e-10, within 1e-6 at 1e-12).  Such problems get the tighter stop by default. */
+    for (c_int i = 0; i < w->data->m; i++)
+      if (w->constr_type[i] == 1) { prm.pcg_eps_rel = HMAX(1e-13, 1e-2 * prm.pcg_eps_rel); break; }
   }
   const c_int adaptive_pcg = g_opt.pcg_adaptive;
   const c_float strict_rel = prm.pcg_eps_rel;
@@ -758,7 +765,7 @@ c_int osqp_solve(OSQPWorkspace *w) {
       if (t >= st->time_limit) {
         put_status(w->info, OSQP_TIME_LIMIT_REACHED);
         if (st->verbose) printf("run time limit reached\n");
-        can_print = 0; can_check = 0;
+        can_print = 0; can_check = 0; timed_out = 1;
         break;
       }
     }
@@ -782,12 +789,13 @@ c_int osqp_solve(OSQPWorkspace *w) {
   }
 
   if (!can_check) {
-    if (!can_print && refresh_info(w, iter, with_obj)) { exitflag = 1; goto done; }
+    /* the reference leaves its loop by `break` on a time limit and then reports iter - 1 (osqp.c:404, 545) */
+    if (!can_print && refresh_info(w, iter - timed_out, with_obj)) { exitflag = 1; goto done; }
     if (st->verbose && !w->summary_printed) { print_line(w); w->summary_printed = 1; }
     decide_termination(w, 0);
   }
   if (!with_obj && solution_exists(w->info)) {
-    if (s->sc_iter != iter && refresh_info(w, iter, 0)) { exitflag = 1; goto done; }
+    if (s->sc_iter != iter - timed_out && refresh_info(w, iter - timed_out, 0)) { exitflag = 1; goto done; }
     w->info->obj_val = s->sc.obj_scaled * (st->scaling ? w->scaling->cinv : 1.0);
   }
   if (st->verbose && !w->summary_printed) { print_line(w); w->summary_printed = 1; }
@@ -811,10 +819,16 @@ c_int osqp_solve(OSQPWorkspace *w) {
   if (w->first_run) w->first_run = 0;
   w->clear_update_time = 1;
   w->rho_update_from_solve = 0;
-  if (st->verbose)
+  if (st->verbose) {
+    hipeng_stats hs;
     printf("status: %s, iterations: %lld, objective: %.4f, run time: %.2es, rho estimate: %.2e\n",
            w->info->status, (long long)w->info->iter, w->info->obj_val, w->info->run_time,
            w->info->rho_estimate);
+    /* an indirect solve that hit its iteration cap (or broke down) was accepted as it stood: say so */
+    if (!hipeng_get_stats(s->eng, &hs) && hs.pcg_forced > 0)
+      printf("warning: %lld linear solve(s) stopped at the PCG iteration cap or on a breakdown before reaching the "
+             "requested accuracy (osqp_amd_get_stats: pcg_forced)\n", (long long)hs.pcg_forced);
+  }
 done:
   return exitflag;
 }

