@@ -33,6 +33,8 @@
 #define HMAX(a, b) (((a) > (b)) ? (a) : (b))
 #define HMIN(a, b) (((a) < (b)) ? (a) : (b))
 #define BOUND_INF (OSQP_INFTY * MIN_SCALING)
+#define POLISH_DELTA_MIN  1e-3   /* regularisation of the polish solves (see run_polish) */
+#define POLISH_MAX_REFINE 15     /* refinement steps at most (the reference's polish_refine_iter at least) */
 
 struct OSQP_TIMER { double t0; };
 
@@ -1024,16 +1026,6 @@ SETTER(osqp_update_time_limit, c_float, time_limit, v >= 0., "time_limit must be
 /* ------------------------------------------------------------------------ */
 /* polish (src/polish.c:19-350) through the plugin with polish = 1            */
 /* ------------------------------------------------------------------------ */
-static void host_spmv(const csc *A, const c_float *x, c_float *y, int sign) {        /* y += sign * A x */
-  for (c_int j = 0; j < A->n; j++)
-    for (c_int k = A->p[j]; k < A->p[j + 1]; k++) y[A->i[k]] += sign * A->x[k] * x[j];
-}
-static void host_spmv_t(const csc *A, const c_float *x, c_float *y, int sign, int skip_diag) { /* y += sign * A' x */
-  for (c_int j = 0; j < A->n; j++)
-    for (c_int k = A->p[j]; k < A->p[j + 1]; k++)
-      if (!(skip_diag && A->i[k] == j)) y[j] += sign * A->x[k] * x[A->i[k]];
-}
-
 static c_int run_polish(OSQPWorkspace *w) {
   OSQPPolish *p = w->pol;
   hip_pcg_solver *s = PCG(w);
@@ -1072,30 +1064,51 @@ static c_int run_polish(OSQPWorkspace *w) {
   Ar->p[n] = cnt;
   p->Ared = Ar;
 
+  /* The reference solves [P + dI, Ar'; Ar, -dI] with d = settings->delta (1e-6) by a direct factorisation and
+   * refines against the unregularised KKT matrix (polish.c:134-181, 232-260).  The indirect plugin solves the
+   * equivalent reduced system (P + dI + Ar'Ar/d) x = rhs1 + Ar'rhs2/d and recovers nu = (Ar x - rhs2)/d: that
+   * difference loses log10(1/d) digits, and cond(K) grows like 1/d, so at d = 1e-6 nothing of nu is left.  The
+   * regularisation only has to be small against the KKT matrix for the refinement to contract (error factor
+   * ~ d/sigma_min per step), so the solves use d = max(delta, 1e-3) -- nu keeps ~9 digits -- and the refinement
+   * runs until the true KKT residual (evaluated on the device) stops falling: same limit point, the solution of
+   * the unregularised system, as the reference's 3 steps at 1e-6. */
+  const c_float delta = HMAX(w->settings->delta, POLISH_DELTA_MIN);
   LinSysSolver *ls = NULL;
-  if (init_linsys_solver(&ls, w->data->P, Ar, w->settings->delta, NULL, w->settings->linsys_solver, 1)) {
+  if (init_linsys_solver(&ls, w->data->P, Ar, delta, NULL, w->settings->linsys_solver, 1)) {
     w->info->status_polish = -1; free_csc(Ar); p->Ared = NULL; return 1;
   }
+  hipeng *pe = ((hip_pcg_solver *)ls)->eng;      /* the polish instance's engine holds P and Ared */
   const c_int N = n + mred;
-  c_float *rhs = zero_vec(N), *sol = zero_vec(N), *res = zero_vec(N);
+  c_float *rhs = zero_vec(N), *sol = zero_vec(N), *res = zero_vec(N), *tmp = zero_vec(N);
   for (c_int j = 0; j < n; j++) rhs[j] = -w->data->q[j];
   for (c_int k = 0; k < p->n_low; k++) rhs[n + k] = w->data->l[p->Alow_to_A[k]];
   for (c_int k = 0; k < p->n_upp; k++) rhs[n + p->n_low + k] = w->data->u[p->Aupp_to_A[k]];
   memcpy(sol, rhs, (size_t)N * sizeof(c_float));
   c_int bad = ls->solve(ls, sol);
-  for (c_int it = 0; !bad && it < w->settings->polish_refine_iter; it++) {   /* polish.c:134-181 */
+  c_float prev = OSQP_INFTY;
+  const c_int max_ref = HMAX(w->settings->polish_refine_iter, POLISH_MAX_REFINE);
+  for (c_int it = 0; !bad && it < max_ref; it++) {   /* polish.c:134-181 */
+    /* res = rhs - [P Ar'; Ar 0] sol, SpMVs on the device */
     memcpy(res, rhs, (size_t)N * sizeof(c_float));
-    host_spmv(w->data->P, sol, res, -1);
-    host_spmv_t(w->data->P, sol, res, -1, 1);
-    host_spmv_t(Ar, sol + n, res, -1, 0);
-    host_spmv(Ar, sol, res + n, -1);
+    bad = hipeng_spmv(pe, 2, sol, tmp);
+    for (c_int j = 0; j < n; j++) res[j] -= tmp[j];
+    if (!bad && mred) {
+      bad = hipeng_spmv(pe, 1, sol + n, tmp);
+      for (c_int j = 0; j < n; j++) res[j] -= tmp[j];
+      if (!bad) bad = hipeng_spmv(pe, 0, sol, tmp);
+      for (c_int k = 0; k < mred; k++) res[n + k] -= tmp[k];
+    }
+    if (bad) break;
+    const c_float nres = absmax(res, N), scale = HMAX(absmax(rhs, N), 1.0);
+    /* at least the reference's polish_refine_iter steps; then stop once converged or no longer contracting */
+    if (it >= w->settings->polish_refine_iter && (nres <= 1e-14 * scale || nres > 0.5 * prev)) break;
+    prev = nres;
     bad = ls->solve(ls, res);
     for (c_int k = 0; k < N; k++) sol[k] += res[k];
   }
   if (bad) { w->info->status_polish = -1; goto cleanup; }
   memcpy(p->x, sol, (size_t)n * sizeof(c_float));
-  for (c_int i = 0; i < m; i++) p->z[i] = 0.0;
-  host_spmv(A, p->x, p->z, +1);
+  if (m && hipeng_spmv(s->eng, 0, p->x, p->z)) { w->info->status_polish = -1; goto cleanup; }   /* z = A x on the device */
   for (c_int i = 0; i < m; i++) {
     if (mred == 0) p->y[i] = 0.0;
     else if (p->A_to_Alow[i] != -1) p->y[i] = sol[n + p->A_to_Alow[i]];
@@ -1143,7 +1156,7 @@ cleanup:
   w->info->polish_time = toc(w->timer);
   ls->free(ls);
   free_csc(Ar); p->Ared = NULL;
-  free(rhs); free(sol); free(res);
+  free(rhs); free(sol); free(res); free(tmp);
   return 0;
 }
 
