@@ -382,13 +382,13 @@ def main():
         if world == 1 and not a.no_inexact:
             # opt-in inexact mode (PCG tolerance tied to the ADMM residuals): NOT parity-exact,
             # reported beside the headline, never as `value`
-            osqp_amd.set_engine_options(pcg_adaptive=1)
+            solver.set_options(pcg_adaptive=1)
             t1 = time.perf_counter(); fi = 0
             for _ in range(a.steps):
                 rf = step(); fi += rf.info.iter
             torch.cuda.synchronize()
             tf = time.perf_counter() - t1
-            osqp_amd.set_engine_options(pcg_adaptive=0)
+            solver.set_options(pcg_adaptive=0)
             out["inexact_mode"] = {"value": round(fi / tf, 2), "unit": "ADMM iters/s", "admm_iters_per_solve": int(rf.info.iter),
                                    "status": rf.info.status, "obj_rel_diff_vs_strict": abs(rf.info.obj_val - last.info.obj_val) / abs(last.info.obj_val),
                                    "note": "OSQP_AMD_PCG_ADAPTIVE=1; results agree with the strict mode only to the ADMM tolerance"}

@@ -13,6 +13,7 @@
 #define OSQP_AMD_H
 
 #include "osqp_amd_types.h"
+#include "osqp_amd_helpers.h"   /* cs.h / lin_alg.h / kkt.h helper symbols, allocator hook */
 
 #ifdef __cplusplus
 extern "C" {
@@ -54,8 +55,8 @@ c_int osqp_update_polish_refine_iter(OSQPWorkspace *work, c_int polish_refine_it
 c_int osqp_update_verbose(OSQPWorkspace *work, c_int verbose_new);
 c_int osqp_update_time_limit(OSQPWorkspace *work, c_float time_limit_new);
 
-/* ---- helpers callers of the reference use (include/cs.h, include/auxil.h) - */
-csc  *csc_matrix(c_int m, c_int n, c_int nzmax, c_float *x, c_int *i, c_int *p); /* cs.h:36 */
+/* ---- helpers callers of the reference use (include/auxil.h; the cs.h / lin_alg.h / kkt.h
+ *      ones are declared in osqp_amd_helpers.h) ------------------------------------------ */
 void  cold_start(OSQPWorkspace *work);                                           /* auxil.h:62 */
 
 /* ---- linear-system plugin boundary (include/lin_sys.h:20-45) -------------
@@ -96,6 +97,11 @@ typedef struct {
   c_int host_syncs;
 } osqp_amd_stats;
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, osqp_amd_stats *st);
+/* The options above are the DEFAULTS a new workspace / plugin instance copies at creation; afterwards
+ * each instance has its own (no knob is shared between live workspaces).  These two read / change the
+ * copy of one workspace (the device cannot be changed after setup). */
+c_int osqp_amd_get_workspace_options(const OSQPWorkspace *work, osqp_amd_options *opt);
+c_int osqp_amd_set_workspace_options(OSQPWorkspace *work, const osqp_amd_options *opt);
 /* Binary problem files: one little-endian file per QP (layout in osqp_host.c); the data the
  * reference's generators emit as C headers (tests/utils/codegen_utils.py:172-347).
  * Return 0, or 1 bad argument / 2 cannot open / 3 malformed / 4 out of memory. */

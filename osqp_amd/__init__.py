@@ -36,6 +36,7 @@ def engine_options():
 
 
 def set_engine_options(**kw):
+    """Defaults for workspaces set up from now on (existing ones keep their own copy: `OSQP.set_options`)."""
     cur = engine_options()
     cur.update(kw)
     o = _Options(**cur)
@@ -59,6 +60,30 @@ class OSQP(SolverHandle):
         if f(self._work, C.byref(s)):
             raise RuntimeError("no engine")
         return {k: getattr(s, k) for k, _ in _Stats._fields_}
+
+    def options(self):
+        """This workspace's engine options (a copy of the defaults taken at setup; `engine_options()` reads the defaults)."""
+        o = _Options()
+        f = self._lib.osqp_amd_get_workspace_options
+        f.restype = abi.c_int
+        f.argtypes = [C.POINTER(abi.OSQPWorkspace), C.POINTER(_Options)]
+        if f(self._work, C.byref(o)):
+            raise RuntimeError("no engine")
+        return {k: getattr(o, k) for k, _ in _Options._fields_}
+
+    def set_options(self, **kw):
+        """Change engine options of THIS workspace only (pcg_eps_rel, pcg_eps_abs, pcg_max_iter, pcg_adaptive)."""
+        cur = self.options()
+        for k in kw:
+            if k not in cur or k == "device":
+                raise ValueError("unknown or fixed option %r" % k)
+        cur.update(kw)
+        o = _Options(**cur)
+        f = self._lib.osqp_amd_set_workspace_options
+        f.restype = abi.c_int
+        f.argtypes = [C.POINTER(abi.OSQPWorkspace), C.POINTER(_Options)]
+        if f(self._work, C.byref(o)):
+            raise RuntimeError("no engine")
 
     def engine(self):
         f = self._lib.osqp_amd_engine

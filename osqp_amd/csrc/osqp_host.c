@@ -29,6 +29,7 @@
 #include <time.h>
 #include "../../include/osqp_amd.h"
 #include "../../include/osqp_amd_engine.h"
+#include "../../include/osqp_amd_helpers.h"
 
 #define HMAX(a, b) (((a) > (b)) ? (a) : (b))
 #define HMIN(a, b) (((a) < (b)) ? (a) : (b))
@@ -47,7 +48,10 @@ static void tic(OSQPTimer *t) { t->t0 = now_s(); }
 static double toc(const OSQPTimer *t) { return now_s() - t->t0; }
 
 /* ------------------------------------------------------------------------ */
-/* process-wide engine options (side channel, see include/osqp_amd.h)        */
+/* engine options (side channel, see include/osqp_amd.h).  g_opt is only the  */
+/* template new solver objects are initialised from (environment + the last   */
+/* osqp_amd_set_options); every workspace / plugin instance carries its own   */
+/* copy, so two workspaces never read each other's knobs after setup.         */
 /* ------------------------------------------------------------------------ */
 static osqp_amd_options g_opt;
 static int g_opt_init = 0;
@@ -68,11 +72,10 @@ static void opt_init(void) {
 void osqp_amd_get_options(osqp_amd_options *o) { opt_init(); *o = g_opt; }
 void osqp_amd_set_options(const osqp_amd_options *o) { opt_init(); g_opt = *o; }
 
-static void fill_params(hipeng_params *p, c_float sigma, c_float alpha, c_int n) {
-  opt_init();
+static void fill_params(hipeng_params *p, const osqp_amd_options *o, c_float sigma, c_float alpha, c_int n) {
   p->sigma = sigma; p->alpha = alpha;
-  p->pcg_eps_rel = g_opt.pcg_eps_rel; p->pcg_eps_abs = g_opt.pcg_eps_abs;
-  p->pcg_max_iter = g_opt.pcg_max_iter > 0 ? g_opt.pcg_max_iter : HMAX(1000, 2 * n);
+  p->pcg_eps_rel = o->pcg_eps_rel; p->pcg_eps_abs = o->pcg_eps_abs;
+  p->pcg_max_iter = o->pcg_max_iter > 0 ? o->pcg_max_iter : HMAX(1000, 2 * n);
   p->no_restart = 0;
 }
 
@@ -98,6 +101,7 @@ typedef struct {
   hipeng_scalars sc;      /* last residual scalars                                */
   c_int sc_iter;          /* iteration they belong to (-1 = stale)                */
   c_int host_syncs;
+  osqp_amd_options opt;   /* this instance's engine options (copied from the defaults at creation) */
 } hip_pcg_solver;
 
 #define PCG(work) ((hip_pcg_solver *)((work)->linsys_solver))
@@ -109,10 +113,9 @@ static c_int pcg_solve(LinSysSolver *self, c_float *b) {
     if (!s->aux) {
       const OSQPWorkspace *w = s->owner;
       hipeng_params prm;
-      fill_params(&prm, w->settings->sigma, w->settings->alpha, w->data->n);
-      opt_init();
+      fill_params(&prm, &s->opt, w->settings->sigma, w->settings->alpha, w->data->n);
       if (hipeng_create(&s->aux, w->data->P, w->data->A, NULL, NULL, NULL, w->rho_vec, &prm,
-                        (int)g_opt.device)) return 1;
+                        (int)s->opt.device)) return 1;
     }
     e = s->aux;
   }
@@ -135,11 +138,10 @@ static void pcg_free(LinSysSolver *self) {
   if (!s) return;
   hipeng_destroy(s->eng);
   hipeng_destroy(s->aux);
-  free(s->rho_tmp);
-  if (s->rawP) { free(s->rawP->p); free(s->rawP->i); free(s->rawP->x); free(s->rawP); }
-  if (s->rawA) { free(s->rawA->p); free(s->rawA->i); free(s->rawA->x); free(s->rawA); }
-  free(s->rawq); free(s->rawl); free(s->rawu);
-  free(s);
+  c_free(s->rho_tmp);
+  csc_spfree(s->rawP); csc_spfree(s->rawA);
+  c_free(s->rawq); c_free(s->rawl); c_free(s->rawu);
+  c_free(s);
 }
 
 static c_int pcg_update_matrices(LinSysSolver *self, const csc *P, const csc *A) {
@@ -158,13 +160,15 @@ static c_int pcg_update_rho_vec(LinSysSolver *self, const c_float *rho_vec) {
 }
 
 static hip_pcg_solver *pcg_alloc(c_int n, c_int m, c_float sigma, c_int polish) {
-  hip_pcg_solver *s = (hip_pcg_solver *)calloc(1, sizeof(hip_pcg_solver));
+  hip_pcg_solver *s = (hip_pcg_solver *)c_calloc(1, sizeof(hip_pcg_solver));
   if (!s) return NULL;
   s->type = HIP_PCG_SOLVER; s->nthreads = 1;
   s->solve = polish ? pcg_solve_polish : pcg_solve;
   s->free = pcg_free;
   s->update_matrices = pcg_update_matrices; s->update_rho_vec = pcg_update_rho_vec;
   s->n = n; s->m = m; s->sigma = sigma; s->polish = polish; s->sc_iter = -1;
+  opt_init();
+  s->opt = g_opt;
   return s;
 }
 
@@ -179,17 +183,16 @@ c_int init_linsys_solver_hip_pcg(LinSysSolver **sp, const csc *P, const csc *A,
   if (!s) return OSQP_LINSYS_SOLVER_INIT_ERROR;
   const c_float *rv = rho_vec;
   if (polish) {
-    s->rho_tmp = (c_float *)malloc((size_t)(2 * A->m + 1) * sizeof(c_float));
-    if (!s->rho_tmp) { free(s); return OSQP_LINSYS_SOLVER_INIT_ERROR; }
+    s->rho_tmp = (c_float *)c_malloc((size_t)(2 * A->m + 1) * sizeof(c_float));
+    if (!s->rho_tmp) { c_free(s); return OSQP_LINSYS_SOLVER_INIT_ERROR; }
     for (c_int i = 0; i < A->m; i++) s->rho_tmp[i] = 1.0 / sigma;
     rv = s->rho_tmp;
   }
   hipeng_params prm;
-  fill_params(&prm, sigma, 1.0, P->n);
+  fill_params(&prm, &s->opt, sigma, 1.0, P->n);
   if (polish) { prm.pcg_eps_rel = HMIN(prm.pcg_eps_rel, 1e-12); }
-  opt_init();
-  if (hipeng_create(&s->eng, P, A, NULL, NULL, NULL, rv, &prm, (int)g_opt.device)) {
-    free(s->rho_tmp); free(s);
+  if (hipeng_create(&s->eng, P, A, NULL, NULL, NULL, rv, &prm, (int)s->opt.device)) {
+    c_free(s->rho_tmp); c_free(s);
     return OSQP_LINSYS_SOLVER_INIT_ERROR;
   }
   *sp = (LinSysSolver *)s;
@@ -211,36 +214,14 @@ c_int init_linsys_solver(LinSysSolver **s, const csc *P, const csc *A, c_float s
 /* small host helpers                                                         */
 /* ------------------------------------------------------------------------ */
 static c_float *dup_vec(const c_float *a, c_int n) {
-  c_float *b = (c_float *)malloc((size_t)(n > 0 ? n : 1) * sizeof(c_float));
+  c_float *b = (c_float *)c_malloc((size_t)(n > 0 ? n : 1) * sizeof(c_float));
   if (b && n > 0) memcpy(b, a, (size_t)n * sizeof(c_float));
   return b;
 }
-static c_float *zero_vec(c_int n) { return (c_float *)calloc((size_t)(n > 0 ? n : 1), sizeof(c_float)); }
+static c_float *zero_vec(c_int n) { return (c_float *)c_calloc((size_t)(n > 0 ? n : 1), sizeof(c_float)); }
 
-static csc *dup_csc(const csc *A) {
-  c_int nnz = A->p[A->n];
-  csc *B = (csc *)calloc(1, sizeof(csc));
-  if (!B) return NULL;
-  B->m = A->m; B->n = A->n; B->nz = -1; B->nzmax = nnz > 0 ? nnz : 1;
-  B->p = (c_int *)malloc((size_t)(A->n + 1) * sizeof(c_int));
-  B->i = (c_int *)malloc((size_t)B->nzmax * sizeof(c_int));
-  B->x = (c_float *)malloc((size_t)B->nzmax * sizeof(c_float));
-  if (!B->p || !B->i || !B->x) { free(B->p); free(B->i); free(B->x); free(B); return NULL; }
-  memcpy(B->p, A->p, (size_t)(A->n + 1) * sizeof(c_int));
-  if (nnz > 0) {
-    memcpy(B->i, A->i, (size_t)nnz * sizeof(c_int));
-    memcpy(B->x, A->x, (size_t)nnz * sizeof(c_float));
-  }
-  return B;
-}
-static void free_csc(csc *A) { if (A) { free(A->p); free(A->i); free(A->x); free(A); } }
-
-csc *csc_matrix(c_int m, c_int n, c_int nzmax, c_float *x, c_int *i, c_int *p) {
-  csc *M = (csc *)malloc(sizeof(csc));
-  if (!M) return NULL;
-  M->m = m; M->n = n; M->nz = -1; M->nzmax = nzmax; M->x = x; M->i = i; M->p = p;
-  return M;
-}
+static csc *dup_csc(const csc *A) { return copy_csc_mat(A); }
+static void free_csc(csc *A) { csc_spfree(A); }
 
 static c_float absmax(const c_float *v, c_int n) {
   c_float b = 0.0;
@@ -415,30 +396,30 @@ void cold_start(OSQPWorkspace *w) {   /* src/auxil.c:155-159 */
 c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings) {
   if (check_data(data)) return setup_fail(OSQP_DATA_VALIDATION_ERROR, "Data validation returned failure");
   if (check_settings(settings)) return setup_fail(OSQP_SETTINGS_VALIDATION_ERROR, "Settings validation returned failure");
-  OSQPWorkspace *w = (OSQPWorkspace *)calloc(1, sizeof(OSQPWorkspace));
+  OSQPWorkspace *w = (OSQPWorkspace *)c_calloc(1, sizeof(OSQPWorkspace));
   if (!w) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
   *workp = w;   /* set early: cleanup after a failed setup must work (osqp.c:88-90) */
   const c_int n = data->n, m = data->m;
-  w->timer = (OSQPTimer *)malloc(sizeof(OSQPTimer));
+  w->timer = (OSQPTimer *)c_malloc(sizeof(OSQPTimer));
   if (!w->timer) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
   tic(w->timer);
 
-  w->data = (OSQPData *)calloc(1, sizeof(OSQPData));
+  w->data = (OSQPData *)c_calloc(1, sizeof(OSQPData));
   if (!w->data) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
   w->data->n = n; w->data->m = m;
   w->data->P = dup_csc(data->P); w->data->A = dup_csc(data->A);
   w->data->q = dup_vec(data->q, n); w->data->l = dup_vec(data->l, m); w->data->u = dup_vec(data->u, m);
   w->rho_vec = zero_vec(m); w->rho_inv_vec = zero_vec(m);
-  w->constr_type = (c_int *)calloc((size_t)(m > 0 ? m : 1), sizeof(c_int));
+  w->constr_type = (c_int *)c_calloc((size_t)(m > 0 ? m : 1), sizeof(c_int));
   w->x = zero_vec(n); w->z = zero_vec(m); w->xz_tilde = zero_vec(n + m);
   w->x_prev = zero_vec(n); w->z_prev = zero_vec(m); w->y = zero_vec(m);
   w->Ax = zero_vec(m); w->Px = zero_vec(n); w->Aty = zero_vec(n);
   w->delta_y = zero_vec(m); w->Atdelta_y = zero_vec(n);
   w->delta_x = zero_vec(n); w->Pdelta_x = zero_vec(n); w->Adelta_x = zero_vec(m);
-  w->settings = (OSQPSettings *)malloc(sizeof(OSQPSettings));
-  w->solution = (OSQPSolution *)calloc(1, sizeof(OSQPSolution));
-  w->info = (OSQPInfo *)calloc(1, sizeof(OSQPInfo));
-  w->pol = (OSQPPolish *)calloc(1, sizeof(OSQPPolish));
+  w->settings = (OSQPSettings *)c_malloc(sizeof(OSQPSettings));
+  w->solution = (OSQPSolution *)c_calloc(1, sizeof(OSQPSolution));
+  w->info = (OSQPInfo *)c_calloc(1, sizeof(OSQPInfo));
+  w->pol = (OSQPPolish *)c_calloc(1, sizeof(OSQPPolish));
   if (!w->data->P || !w->data->A || !w->data->q || !w->data->l || !w->data->u || !w->rho_vec ||
       !w->rho_inv_vec || !w->constr_type || !w->x || !w->z || !w->xz_tilde || !w->x_prev ||
       !w->z_prev || !w->y || !w->Ax || !w->Px || !w->Aty || !w->delta_y || !w->Atdelta_y ||
@@ -447,15 +428,15 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
   *w->settings = *settings;
   w->solution->x = zero_vec(n); w->solution->y = zero_vec(m);
   size_t mm = (size_t)(m > 0 ? m : 1);
-  w->pol->Alow_to_A = (c_int *)malloc(mm * sizeof(c_int)); w->pol->Aupp_to_A = (c_int *)malloc(mm * sizeof(c_int));
-  w->pol->A_to_Alow = (c_int *)malloc(mm * sizeof(c_int)); w->pol->A_to_Aupp = (c_int *)malloc(mm * sizeof(c_int));
+  w->pol->Alow_to_A = (c_int *)c_malloc(mm * sizeof(c_int)); w->pol->Aupp_to_A = (c_int *)c_malloc(mm * sizeof(c_int));
+  w->pol->A_to_Alow = (c_int *)c_malloc(mm * sizeof(c_int)); w->pol->A_to_Aupp = (c_int *)c_malloc(mm * sizeof(c_int));
   w->pol->x = zero_vec(n); w->pol->z = zero_vec(m); w->pol->y = zero_vec(m);
   if (!w->solution->x || !w->solution->y || !w->pol->Alow_to_A || !w->pol->Aupp_to_A ||
       !w->pol->A_to_Alow || !w->pol->A_to_Aupp || !w->pol->x || !w->pol->z || !w->pol->y)
     return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
 
   if (settings->scaling) {
-    w->scaling = (OSQPScaling *)calloc(1, sizeof(OSQPScaling));
+    w->scaling = (OSQPScaling *)c_calloc(1, sizeof(OSQPScaling));
     if (!w->scaling) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
     w->scaling->D = zero_vec(n); w->scaling->Dinv = zero_vec(n);
     w->scaling->E = zero_vec(m); w->scaling->Einv = zero_vec(m);
@@ -478,10 +459,9 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
       return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
   }
   hipeng_params prm;
-  fill_params(&prm, w->settings->sigma, w->settings->alpha, n);
-  opt_init();
+  fill_params(&prm, &s->opt, w->settings->sigma, w->settings->alpha, n);
   int rc = hipeng_create(&s->eng, w->data->P, w->data->A, w->data->q, w->data->l, w->data->u,
-                         NULL, &prm, (int)g_opt.device);
+                         NULL, &prm, (int)s->opt.device);
   if (rc == HIPENG_ERR_NO_DEVICE)
     return setup_fail(OSQP_LINSYS_SOLVER_LOAD_ERROR, "no HIP device: the HIP PCG solver cannot be loaded");
   if (rc) return setup_fail(OSQP_LINSYS_SOLVER_INIT_ERROR, "HIP engine initialisation failed");
@@ -501,7 +481,7 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
     c_int probe = HMIN(HMAX(2 * n, 8), 300);
     hipeng_params pp = prm;
     pp.pcg_max_iter = probe; pp.no_restart = 1;
-    c_float *rhs = (c_float *)malloc((size_t)(n + m + 1) * sizeof(c_float));
+    c_float *rhs = (c_float *)c_malloc((size_t)(n + m + 1) * sizeof(c_float));
     unsigned long long lcg = 88172645463325252ULL;
     if (!rhs) return setup_fail(OSQP_MEM_ALLOC_ERROR, "Memory allocation failed");
     for (c_int k = 0; k < n + m; k++) {
@@ -510,7 +490,7 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
     }
     hipeng_stats hs;
     int bad = hipeng_set_params(s->eng, &pp) || hipeng_kkt_solve(s->eng, rhs) || hipeng_get_stats(s->eng, &hs);
-    free(rhs);
+    c_free(rhs);
     if (bad) return setup_fail(OSQP_LINSYS_SOLVER_INIT_ERROR, "HIP engine initialisation failed");
     if (hs.neg_curvature > 0)
       return setup_fail(OSQP_NONCVX_ERROR, "KKT matrix factorization.\nThe problem seems to be non-convex");
@@ -537,25 +517,25 @@ c_int osqp_cleanup(OSQPWorkspace *w) {   /* src/osqp.c:659-757 */
   if (!w) return 0;
   if (w->data) {
     free_csc(w->data->P); free_csc(w->data->A);
-    free(w->data->q); free(w->data->l); free(w->data->u); free(w->data);
+    c_free(w->data->q); c_free(w->data->l); c_free(w->data->u); c_free(w->data);
   }
   if (w->scaling) {
-    free(w->scaling->D); free(w->scaling->Dinv); free(w->scaling->E); free(w->scaling->Einv);
-    free(w->scaling);
+    c_free(w->scaling->D); c_free(w->scaling->Dinv); c_free(w->scaling->E); c_free(w->scaling->Einv);
+    c_free(w->scaling);
   }
-  free(w->D_temp); free(w->D_temp_A); free(w->E_temp);
+  c_free(w->D_temp); c_free(w->D_temp_A); c_free(w->E_temp);
   if (w->linsys_solver && w->linsys_solver->free) w->linsys_solver->free(w->linsys_solver);
   if (w->pol) {
-    free(w->pol->Alow_to_A); free(w->pol->Aupp_to_A); free(w->pol->A_to_Alow); free(w->pol->A_to_Aupp);
-    free(w->pol->x); free(w->pol->z); free(w->pol->y); free(w->pol);
+    c_free(w->pol->Alow_to_A); c_free(w->pol->Aupp_to_A); c_free(w->pol->A_to_Alow); c_free(w->pol->A_to_Aupp);
+    c_free(w->pol->x); c_free(w->pol->z); c_free(w->pol->y); c_free(w->pol);
   }
-  free(w->rho_vec); free(w->rho_inv_vec); free(w->constr_type);
-  free(w->x); free(w->z); free(w->xz_tilde); free(w->x_prev); free(w->z_prev); free(w->y);
-  free(w->Ax); free(w->Px); free(w->Aty); free(w->delta_y); free(w->Atdelta_y);
-  free(w->delta_x); free(w->Pdelta_x); free(w->Adelta_x);
-  free(w->settings);
-  if (w->solution) { free(w->solution->x); free(w->solution->y); free(w->solution); }
-  free(w->info); free(w->timer); free(w);
+  c_free(w->rho_vec); c_free(w->rho_inv_vec); c_free(w->constr_type);
+  c_free(w->x); c_free(w->z); c_free(w->xz_tilde); c_free(w->x_prev); c_free(w->z_prev); c_free(w->y);
+  c_free(w->Ax); c_free(w->Px); c_free(w->Aty); c_free(w->delta_y); c_free(w->Atdelta_y);
+  c_free(w->delta_x); c_free(w->Pdelta_x); c_free(w->Adelta_x);
+  c_free(w->settings);
+  if (w->solution) { c_free(w->solution->x); c_free(w->solution->y); c_free(w->solution); }
+  c_free(w->info); c_free(w->timer); c_free(w);
   return 0;
 }
 
@@ -720,7 +700,7 @@ c_int osqp_solve(OSQPWorkspace *w) {
   if (st->verbose) printf("iter   objective    pri res    dua res    rho        time\n");
 
   hipeng_params prm;
-  fill_params(&prm, st->sigma, st->alpha, w->data->n);
+  fill_params(&prm, &s->opt, st->sigma, st->alpha, w->data->n);
   /* opt-in inexact mode (not parity-exact): the linear solves are only as accurate as the ADMM
    * iterate needs -- PCG stops at lambda * sqrt(||r_prim|| * ||r_dual||) (scaled residuals of the
    * last evaluation), the rule of Schubiger, Banjac, Lygeros (JPDC 144, 2020) cited by the
@@ -738,7 +718,7 @@ c_int osqp_solve(OSQPWorkspace *w) {
     for (c_int i = 0; i < w->data->m; i++)
       if (w->constr_type[i] == 1) { prm.pcg_eps_rel = HMAX(1e-13, 1e-2 * prm.pcg_eps_rel); break; }
   }
-  const c_int adaptive_pcg = g_opt.pcg_adaptive;
+  const c_int adaptive_pcg = s->opt.pcg_adaptive;
   const c_float strict_rel = prm.pcg_eps_rel;
   if (adaptive_pcg) prm.pcg_eps_rel = 1e-3;
   if (hipeng_set_params(s->eng, &prm)) { exitflag = 1; goto done; }
@@ -1046,12 +1026,12 @@ static c_int run_polish(OSQPWorkspace *w) {
   c_int cnt = 0;
   for (c_int k = 0; k < A->p[n]; k++)
     if (p->A_to_Alow[A->i[k]] != -1 || p->A_to_Aupp[A->i[k]] != -1) cnt++;
-  csc *Ar = (csc *)calloc(1, sizeof(csc));
+  csc *Ar = (csc *)c_calloc(1, sizeof(csc));
   if (!Ar) { w->info->status_polish = -1; return -1; }
   Ar->m = mred; Ar->n = n; Ar->nz = -1; Ar->nzmax = cnt > 0 ? cnt : 1;
-  Ar->p = (c_int *)calloc((size_t)n + 1, sizeof(c_int));
-  Ar->i = (c_int *)calloc((size_t)Ar->nzmax, sizeof(c_int));
-  Ar->x = (c_float *)calloc((size_t)Ar->nzmax, sizeof(c_float));
+  Ar->p = (c_int *)c_calloc((size_t)n + 1, sizeof(c_int));
+  Ar->i = (c_int *)c_calloc((size_t)Ar->nzmax, sizeof(c_int));
+  Ar->x = (c_float *)c_calloc((size_t)Ar->nzmax, sizeof(c_float));
   cnt = 0;
   for (c_int j = 0; j < n; j++) {
     Ar->p[j] = cnt;
@@ -1156,7 +1136,7 @@ cleanup:
   w->info->polish_time = toc(w->timer);
   ls->free(ls);
   free_csc(Ar); p->Ared = NULL;
-  free(rhs); free(sol); free(res); free(tmp);
+  c_free(rhs); c_free(sol); c_free(res); c_free(tmp);
   return 0;
 }
 
@@ -1190,7 +1170,7 @@ c_int osqp_amd_write_problem(const char *path, const OSQPData *d) {
 void osqp_amd_free_problem(OSQPData *d) {
   if (!d) return;
   free_csc(d->P); free_csc(d->A);
-  free(d->q); free(d->l); free(d->u); free(d);
+  c_free(d->q); c_free(d->l); c_free(d->u); c_free(d);
 }
 
 c_int osqp_amd_read_problem(const char *path, OSQPData **out) {
@@ -1202,19 +1182,19 @@ c_int osqp_amd_read_problem(const char *path, OSQPData **out) {
   c_int hdr[4];
   if (fread(magic, 1, 8, f) != 8 || memcmp(magic, PROBLEM_MAGIC, 8) || fread(hdr, sizeof(c_int), 4, f) != 4 ||
       hdr[0] <= 0 || hdr[1] < 0 || hdr[2] < 0 || hdr[3] < 0) { fclose(f); return 3; }
-  OSQPData *d = (OSQPData *)calloc(1, sizeof(OSQPData));
+  OSQPData *d = (OSQPData *)c_calloc(1, sizeof(OSQPData));
   if (!d) { fclose(f); return 4; }
   d->n = hdr[0]; d->m = hdr[1];
   int ok = 1;
   for (int k = 0; ok && k < 2; k++) {
     const c_int nnz = hdr[2 + k];
-    csc *M = (csc *)calloc(1, sizeof(csc));
+    csc *M = (csc *)c_calloc(1, sizeof(csc));
     if (!M) { ok = 0; break; }
     if (k == 0) d->P = M; else d->A = M;
     M->m = k == 0 ? d->n : d->m; M->n = d->n; M->nz = -1; M->nzmax = nnz > 0 ? nnz : 1;
-    M->p = (c_int *)malloc(((size_t)d->n + 1) * sizeof(c_int));
-    M->i = (c_int *)malloc((size_t)M->nzmax * sizeof(c_int));
-    M->x = (c_float *)malloc((size_t)M->nzmax * sizeof(c_float));
+    M->p = (c_int *)c_malloc(((size_t)d->n + 1) * sizeof(c_int));
+    M->i = (c_int *)c_malloc((size_t)M->nzmax * sizeof(c_int));
+    M->x = (c_float *)c_malloc((size_t)M->nzmax * sizeof(c_float));
     ok = M->p && M->i && M->x && fread(M->p, sizeof(c_int), (size_t)d->n + 1, f) == (size_t)d->n + 1 &&
          fread(M->i, sizeof(c_int), (size_t)nnz, f) == (size_t)nnz &&
          fread(M->x, sizeof(c_float), (size_t)nnz, f) == (size_t)nnz && M->p[d->n] == nnz;
@@ -1240,6 +1220,20 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, osqp_amd_stats *out) {
   out->pcg_iters_total = hs.pcg_iters_total; out->pcg_iters_last = hs.pcg_iters_last;
   out->pcg_forced = hs.pcg_forced; out->graph_launches = hs.graph_launches;
   out->host_syncs = s->host_syncs;
+  return 0;
+}
+
+/* per-workspace engine options (device excluded: the engine lives where it was created) */
+c_int osqp_amd_get_workspace_options(const OSQPWorkspace *w, osqp_amd_options *o) {
+  if (!w || !w->linsys_solver || !o) return 1;
+  *o = PCG(w)->opt;
+  return 0;
+}
+c_int osqp_amd_set_workspace_options(OSQPWorkspace *w, const osqp_amd_options *o) {
+  if (!w || !w->linsys_solver || !o) return 1;
+  const c_int dev = PCG(w)->opt.device;
+  PCG(w)->opt = *o;
+  PCG(w)->opt.device = dev;
   return 0;
 }
 

@@ -28,7 +28,7 @@ def product_lib():
     return osqp_amd.lib()
 
 
-@pytest.mark.parametrize("header", ["osqp_amd.h", "osqp_amd_engine.h", "osqp_amd_batch.h"])
+@pytest.mark.parametrize("header", ["osqp_amd.h", "osqp_amd_engine.h", "osqp_amd_batch.h", "osqp_amd_helpers.h"])
 def test_library_exports_every_declared_symbol(product_lib, header):
     names = _declared_functions(header)
     assert len(names) >= 6

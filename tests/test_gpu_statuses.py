@@ -179,3 +179,25 @@ def test_ill_conditioned_convex_accepted_at_setup(gpu_lib, oracle_mod):
     rg = sg.solve()
     assert rg.info.status == ro.info.status == "solved" and rg.info.iter == ro.info.iter
     assert _rel(rg.x, ro.x) < 1e-4 and abs(rg.info.obj_val - ro.info.obj_val) <= 1e-6 * max(1.0, abs(ro.info.obj_val))
+
+
+def test_engine_options_are_per_workspace(gpu_lib):
+    """The side-channel knobs (include/osqp_amd.h) are copied into a workspace at setup: changing the defaults
+    or another workspace's copy afterwards does not reach it (no process-global state is read at solve time)."""
+    import osqp_amd
+    from osqp_amd.problems import demo_qp
+    base = osqp_amd.engine_options()
+    s1 = osqp_amd.OSQP().setup(**demo_qp())
+    try:
+        osqp_amd.set_engine_options(pcg_adaptive=1, pcg_eps_rel=1e-9)
+        s2 = osqp_amd.OSQP().setup(**demo_qp())
+    finally:
+        osqp_amd.set_engine_options(**{k: base[k] for k in ("pcg_adaptive", "pcg_eps_rel")})
+    assert s1.options()["pcg_adaptive"] == 0 and s1.options()["pcg_eps_rel"] == base["pcg_eps_rel"]
+    assert s2.options()["pcg_adaptive"] == 1 and s2.options()["pcg_eps_rel"] == 1e-9
+    s1.set_options(pcg_eps_rel=1e-12)
+    assert s1.options()["pcg_eps_rel"] == 1e-12 and s2.options()["pcg_eps_rel"] == 1e-9
+    assert osqp_amd.engine_options() == base
+    with pytest.raises(ValueError):
+        s1.set_options(device=3)
+    assert s1.solve().info.status == "solved" and s2.solve().info.status == "solved"
