@@ -186,14 +186,10 @@ def bench_batch(batch, dist, rank, local_rank, world, coll_dev, steps=10, with_c
         dist.barrier()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    r = bs.results()
-    rec = np.concatenate([r.x, r.y, r.info_raw], axis=1)
-    if dist is not None:      # the one collective of the batch path: gather of the per-QP records
-        pad = np.zeros((per, rec.shape[1])); pad[:rec.shape[0]] = rec
-        t = torch.from_numpy(pad).to(coll_dev)
-        out = torch.empty((world * per, rec.shape[1]), dtype=t.dtype, device=t.device)
+    if dist is not None:      # the one collective of the batch path: gather of the per-QP records, device to device
+        from osqp_amd.dist import gather_batch_records
         tg = time.perf_counter()
-        dist.all_gather_into_tensor(out, t)
+        out = gather_batch_records(bs, per, world, coll_dev)
         torch.cuda.synchronize()
         gather_ms = 1e3 * (time.perf_counter() - tg)
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
@@ -201,6 +197,8 @@ def bench_batch(batch, dist, rank, local_rank, world, coll_dev, steps=10, with_c
         dt = float(tt.item())
         rec = out.cpu().numpy()[:batch]
     else:
+        r = bs.results()
+        rec = np.concatenate([r.x, r.y, r.info_raw], axis=1)
         gather_ms = 0.0
     status = rec[:, s["n"] + s["m"] + 1]
     iters = rec[:, s["n"] + s["m"]]
@@ -291,9 +289,16 @@ def main():
     a = parse()
     if a.cpu_batch_worker:
         return cpu_batch_worker(a.cpu_batch_worker)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not started by a launcher: start one process per GPU ourselves (before anything touches the GPU)
+        # and relay rank 0's JSON line; the children see WORLD_SIZE and take the branch below
+        from osqp_amd.launch import spawn_ranks
+        sys.exit(spawn_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, a.gpus) and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: running %d rank(s)" % (a.gpus, world, world), file=sys.stderr)
     import torch
     dist = None
     ndev = max(1, torch.cuda.device_count())

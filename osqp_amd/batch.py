@@ -100,6 +100,22 @@ class BatchOSQP:
             setattr(out, name, col.astype(np.int64) if name in ("iter", "status_val", "rho_updates") else col)
         return out
 
+    def device_arrays(self):
+        """The result arrays as they sit in HBM -- X [B, n], Y [B, m], info8 [B, 8] -- as objects carrying
+        `__cuda_array_interface__` (no copy; `torch.as_tensor(a, device="cuda")` wraps them for a device-side
+        gather).  Valid until the next solve / cleanup."""
+        f = self._lib.osqp_amd_batch_device_ptrs
+        f.restype = abi.c_int
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        px, py, pi = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        if f(self._h, C.byref(px), C.byref(py), C.byref(pi)):
+            raise RuntimeError("osqp_amd_batch_device_ptrs failed")
+
+        class _Dev:
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = dict(shape=shape, typestr="<f8", data=(int(ptr), False), version=2, strides=None)
+        return _Dev(px.value, (self.B, self.n)), _Dev(py.value, (self.B, max(self.m, 1))), _Dev(pi.value, (self.B, 8))
+
     def cleanup(self):
         if self._h is not None:
             self._lib.osqp_amd_batch_cleanup(self._h)

@@ -42,3 +42,24 @@ def sharded_batch_solve(local_solve, Q, L, U, group=None, device=None):
         full = out.cpu().numpy()
     full = full[:B]
     return full[:, :n], full[:, n:n + m], full[:, n + m:]
+
+
+def gather_batch_records(bs, per, world, coll_dev):
+    """The one collective of the batch path, device to device: the rank's result arrays are wrapped where they sit in
+    HBM (BatchOSQP.device_arrays), packed into `per` records [x | y | info8] by a device-side concatenation and
+    gathered with ONE all_gather_into_tensor (RCCL over xGMI when `coll_dev` is a cuda device).  With a CPU collective
+    device (gloo rehearsal) the packed records take one D2H copy first.  Returns the [world * per, n + m + 8] tensor."""
+    import torch
+    import torch.distributed as dist
+    torch.cuda.synchronize()          # the batch engine writes the arrays on its own stream
+    X, Y, I = (torch.as_tensor(a, device="cuda") for a in bs.device_arrays())
+    rec = torch.zeros((per, bs.n + bs.m + 8), dtype=torch.float64, device=X.device)
+    rec[:bs.B, :bs.n] = X
+    if bs.m:
+        rec[:bs.B, bs.n:bs.n + bs.m] = Y[:, :bs.m]
+    rec[:bs.B, bs.n + bs.m:] = I
+    if coll_dev.type != "cuda":
+        rec = rec.cpu()
+    out = torch.empty((world * per, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, rec)
+    return out

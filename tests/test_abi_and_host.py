@@ -190,3 +190,36 @@ def test_binary_problem_file_round_trip(product_lib, tmp_path):
     bad = tmp_path / "bad.bin"
     bad.write_bytes(b"OSQPAMD1" + b"\x00" * 16)
     assert L.osqp_amd_read_problem(str(bad).encode(), C.byref(d)) == 3
+
+
+def test_spawn_ranks_sets_env_and_relays_rank0(tmp_path):
+    """`bench.py --gpus N` without a launcher starts N ranks itself (osqp_amd/launch.py): every child gets
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, only rank 0's stdout is relayed, the exit code
+    is the largest of the children's."""
+    import io, json
+    from osqp_amd.launch import spawn_ranks
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys, json\n"
+                     "r = int(os.environ['RANK'])\n"
+                     "open(os.path.join(sys.argv[1], 'rank%d.json' % r), 'w').write(json.dumps({k: os.environ[k] for k in "
+                     "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}))\n"
+                     "print(json.dumps({'n_gpus': int(os.environ['WORLD_SIZE']), 'rank': r}))\n"
+                     "sys.exit(3 if r == 2 and len(sys.argv) > 2 else 0)\n")
+    buf = io.StringIO()
+    assert spawn_ranks(3, [sys.executable, str(child), str(tmp_path)], stdout=buf) == 0
+    assert json.loads(buf.getvalue()) == {"n_gpus": 3, "rank": 0}
+    envs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(3)]
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] == [e["LOCAL_RANK"] for e in envs]
+    assert all(e["WORLD_SIZE"] == "3" and e["MASTER_ADDR"] == "127.0.0.1" for e in envs)
+    assert len({e["MASTER_PORT"] for e in envs}) == 1
+    assert spawn_ranks(3, [sys.executable, str(child), str(tmp_path), "fail"], stdout=io.StringIO()) == 3
+
+
+def test_bench_spawns_before_touching_the_gpu():
+    """bench.py must start its ranks before torch / the HIP library are imported in the parent (a process that
+    initialised the GPU must not fork workers that use it)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("spawn_ranks(") < main.index("import torch") < main.index("import osqp_amd")
+    head = src[:src.index("def parse():")]
+    assert "import torch" not in head and "import osqp_amd" not in head
