@@ -54,13 +54,12 @@ def parse():
 
 def kernel_roofline(solver, reps=300):
     import osqp_amd
-    from osqp_amd import abi
     L = osqp_amd.lib()
     L.hipeng_time_kernel.restype = C.c_int
     L.hipeng_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.hipeng_kernel_bytes.restype = C.c_int
     L.hipeng_kernel_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
-    names = ["k_cg_A", "k_cg_B"] if os.environ.get("OSQP_AMD_PCG_VARIANT", "1") == "1" else ["k_pcg_Ap", "k_pcg_Kp", "k_pcg_update"]
+    names = ["k_cg_A", "k_cg_B"]
     rows = []
     for which in range(len(names)):
         us = C.c_double(); by = C.c_double()
@@ -68,26 +67,36 @@ def kernel_roofline(solver, reps=300):
         assert L.hipeng_kernel_bytes(solver.engine(), which, C.byref(by)) == 0
         rows.append(dict(kernel=names[which], usec=us.value, bytes=by.value,
                          gbs=by.value / (us.value * 1e-6) / 1e9))
+    pair = C.c_double()
+    assert L.hipeng_time_kernel(solver.engine(), 6, reps, C.byref(pair)) == 0       # A then B, as the loop launches them
     dom = max(rows, key=lambda r: r["usec"])
-    # HBM-side traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    # --pmc WRITE_SIZE, separate runs; profiles/r01_*_pmc_and_durations.json), same workload only
-    traffic = None
+    # HBM-side traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate
+    # runs, same workload), corrected as the calibration run prescribes: bytes = 2 x FETCH_SIZE + WRITE_SIZE
+    # (profiles/r02_fetch_calibration.json: FETCH_SIZE tallies 128-byte requests at 64 B)
+    traffic, src = None, None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_and_durations.json")))
+        src = "profiles/r02_config2_pmc_and_durations.json"
+        prof = json.load(open(os.path.join(ROOT, src)))
         if (solver.n, solver.m) == (10000, 20000):
             k = [v for kk, v in prof["kernels"].items() if kk.startswith(dom["kernel"])][0]
-            traffic = round(1024.0 * (k["FETCH_SIZE_KB"]["median"] + k["WRITE_SIZE_KB"]["median"]), 1)
+            traffic = float(k["traffic_bytes_corrected"])
     except Exception:
         traffic = None
+    # algorithmic bytes of one PCG iteration, B_pcg = 2 S_A + S_P + 8 (10 n + 3 m)
+    n, m = solver.n, solver.m
+    b_pcg = 2 * (solver.nnzA * 12 + (m + 1) * 4) + (solver.nnzP * 12 + (n + 1) * 4) + 8 * (10 * n + 3 * m)
     return dict(bound="hbm", achieved=round(dom["gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(dom["gbs"] / HBM_PEAK_GBS, 5), traffic=traffic, kernel=dom["kernel"],
-                traffic_note="bytes/launch = FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes, "
-                             "uncorrected (4/8-byte-per-lane loads are outside the guide's calibrated 16 B pattern)",
+                traffic_note="HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes (%s); "
+                             "the factor 2 on FETCH_SIZE is measured in profiles/r02_fetch_calibration.json" % src,
                 bytes_per_launch=dom["bytes"], usec_per_launch=round(dom["usec"], 3),
                 note="launch-to-launch period of %d graph-captured back-to-back launches (includes the "
                      "dependent-kernel boundary); the 8 MB working set is L2/Infinity-Cache resident" % reps,
                 all_kernels=[dict(kernel=r["kernel"], usec=round(r["usec"], 3), gbs=round(r["gbs"], 2))
-                             for r in rows])
+                             for r in rows],
+                pcg_iteration=dict(usec=round(pair.value, 3), survey_B_pcg_bytes=b_pcg,
+                                   gbs=round(b_pcg / pair.value / 1e3, 2), frac=round(b_pcg / pair.value / 1e3 / HBM_PEAK_GBS, 5),
+                                   note="one PCG iteration = k_cg_A + k_cg_B in loop order; bytes = SURVEY 8(d) B_pcg"))
 
 
 def other_configs(eps):
@@ -103,8 +112,9 @@ def other_configs(eps):
     L.hipeng_kernel_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     out = {}
     for name, make, kw in (("config5_portfolio_n50000", lambda: portfolio_qp(), {}),
-                           ("config3_lasso_5000x10000", lambda: {k: v for k, v in lasso_qp().items() if k in "PqAlu"}, dict(max_iter=200))):
-        pb = make()
+                           ("config3_lasso_5000x10000", lambda: lasso_qp(), {})):
+        full = make()
+        pb = {k: v for k, v in full.items() if k in "PqAlu"}
         t0 = time.perf_counter()
         s = osqp_amd.OSQP().setup(**pb, eps_abs=eps, eps_rel=eps, **kw)
         ts = time.perf_counter() - t0
@@ -127,6 +137,29 @@ def other_configs(eps):
                          admm_iters_per_s=round(r.info.iter / tv, 1),
                          pcg_iters_per_admm_iter=round(st["pcg_iters_total"] / max(1, r.info.iter), 1),
                          usec_per_pcg_iter=round(1e6 * tv / max(1, st["pcg_iters_total"]), 1), pcg_kernels=rows)
+        if name.startswith("config3"):
+            # BASELINE config 3 / SURVEY 8(d): the gamma sweep through osqp_update_lin_cost with warm-started re-solves
+            # (docs/examples/lasso.rst:41-63), then perturbed data through osqp_update_A (same pattern) and a warm-started
+            # solve (src/osqp.c:1092-1169); update time and iteration rate reported separately, every solve run to `solved`
+            from scipy import sparse as _sp
+            nf, md = full["n_feat"], full["m_data"]
+            sweep = []
+            for gamma in (4.0, 7.0, 10.0):
+                q = np.concatenate([np.zeros(nf + md), gamma * np.ones(nf)])
+                t0 = time.perf_counter(); s.update(q=q); tu = time.perf_counter() - t0
+                t0 = time.perf_counter(); rr = s.solve(); tsol = time.perf_counter() - t0
+                sweep.append(dict(gamma=gamma, update_ms=round(1e3 * tu, 3), status=rr.info.status, admm_iters=int(rr.info.iter),
+                                  solve_s=round(tsol, 4), admm_iters_per_s=round(rr.info.iter / tsol, 1)))
+            A = _sp.csc_matrix(pb["A"]); A.sort_indices()
+            Ax_new = A.data * (1.0 + 0.01 * np.random.default_rng(0).standard_normal(A.nnz))
+            t0 = time.perf_counter(); rcu = s.update(Ax=Ax_new); tu = time.perf_counter() - t0
+            t0 = time.perf_counter(); rr = s.solve(); tsol = time.perf_counter() - t0
+            out[name]["gamma_sweep_warm_started"] = sweep
+            out[name]["update_A_then_warm_solve"] = dict(update_rc=int(rcu), update_A_ms=round(1e3 * tu, 2), nnz_updated=int(A.nnz),
+                                                         status=rr.info.status, admm_iters=int(rr.info.iter), solve_s=round(tsol, 4),
+                                                         admm_iters_per_s=round(rr.info.iter / tsol, 1),
+                                                         note="osqp_update_A: 7.5 M values host -> device, re-equilibration on the device, "
+                                                              "mirrors back (src/osqp.c:1092-1169); the solve starts from the previous iterates")
         try:      # the CPU direct solver on the same problem, recorded once by tools/make_config{3,5}_golden.py
             g = json.load(open(os.path.join(ROOT, "tests", "golden", name.split("_")[0] + "_oracle.json")))["info"]
             out[name]["cpu_oracle_recorded"] = dict(admm_iters=g["iters"], admm_iters_per_s=round(g["its"], 2), setup_s=round(g["setup_s"], 1),
@@ -136,6 +169,17 @@ def other_configs(eps):
             pass
         del s
     return out
+
+
+def _recorded(cfg):
+    """The oracle's full-size run of a config, recorded once in the build container (tests/golden/<cfg>_oracle.json)."""
+    try:
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", cfg + "_oracle.json")))["info"]
+        return dict(admm_iters=g["iters"], admm_iters_per_s=round(g["its"], 3), setup_s=round(g["setup_s"], 1), solve_s=round(g["solve_s"], 1),
+                    nnzL=g.get("nnzL"), cores=1, where="build container, the benchmarked instance at full size, solved to eps 1e-4 "
+                                                       "(direct LDL^T; fill of the ordering checked in profiles/r02_nnzL_oracle_vs_mmd.txt)")
+    except Exception:
+        return None
 
 
 def cpu_baseline(n, eps):
@@ -161,7 +205,7 @@ def cpu_baseline(n, eps):
                        "%d solves, each osqp_update_rho(0.1) + cold-started osqp_solve (so the in-solve rho update "
                        "and its re-factorisation are included, as on the GPU); setup (ordering+factor) %.2fs excluded"
                        % (n, 2 * n, runs, t_setup),
-                setup_s=round(t_setup, 3), host_cpus=os.cpu_count())
+                setup_s=round(t_setup, 3), host_cpus=os.cpu_count(), recorded_full_size=_recorded("config2"))
 
 
 def bench_batch(batch, dist, rank, local_rank, world, coll_dev, steps=10, with_cpu=True):
@@ -202,10 +246,25 @@ def bench_batch(batch, dist, rank, local_rank, world, coll_dev, steps=10, with_c
         gather_ms = 0.0
     status = rec[:, s["n"] + s["m"] + 1]
     iters = rec[:, s["n"] + s["m"]]
+    # roofline of the batch kernel: it lives in LDS (one workgroup per QP, nothing leaves the CU in the loop), so the
+    # bound is LDS bandwidth.  Per ADMM iteration a QP reads/writes in LDS: the K^-1 GEMV input (n), two sparse passes over
+    # A (values + patterns + gathered vectors: ~4 words per entry), the z/y/w/x updates (~12 vectors of n or m) and the
+    # exchange buffers: bytes/iter = 8 * (4 * 2 * nnzA + 12 * (n + m)) (+ the register-resident K^-1: 0 LDS bytes).
+    nnzA_b = int(s["A"].nnz)
+    lds_bytes_iter = 8.0 * (4 * 2 * nnzA_b + 12 * (s["n"] + s["m"]))
+    tot_iters = float(iters.sum())
+    lds_peak = 256 * 128 * 2.4e9 / 1e9        # 256 CUs x 128 B/clk x 2.4 GHz = 78.6 TB/s (MI355X_MICROARCH.md: LDS 64-256 B/clk by instruction; 128 B/clk for b64 accesses)
+    flops_iter = 2.0 * s["n"] * s["n"] + 4.0 * 2 * nnzA_b + 20.0 * (s["n"] + s["m"])
     out = dict(metric="QPs/sec (batch)", value=round(batch / dt, 1), unit="QPs/s", batch=batch,
                n=s["n"], m=s["m"], ms_per_batch=round(1e3 * dt, 4), solved=int((status == 1).sum()),
                mean_iters=round(float(iters.mean()), 2), max_iters=int(iters.max()),
                gather_ms=round(gather_ms, 3),
+               roofline=dict(bound="lds", achieved=round(lds_bytes_iter * tot_iters / dt / 1e9, 1), peak=round(lds_peak, 1), unit="GB/s",
+                             frac=round(lds_bytes_iter * tot_iters / dt / 1e9 / lds_peak, 4), traffic=None,
+                             fp64_gflops=round(flops_iter * tot_iters / dt / 1e9, 1),
+                             note="LDS-resident kernel: algorithmic LDS bytes per ADMM iteration per QP = 8 (8 nnzA + 12 (n + m)) "
+                                  "x iterations of all QPs / batch time, against 256 CUs x 128 B/clk x 2.4 GHz; the kernel is bound by "
+                                  "barrier/LDS latency of one workgroup per CU (slowest QP: DESIGN.md), not by either roofline"),
                note="one 512-thread workgroup per QP; cold-started solves (warm_start=0) on the set-up batch "
                     "(scaled data + K^-1 resident in HBM, like the reference's workspace); results left in HBM")
     if world == 1:
@@ -253,7 +312,11 @@ def bench_batch(batch, dist, rank, local_rank, world, coll_dev, steps=10, with_c
                                    sample="first %d QPs of the batch, solve only (setup excluded), %d passes" % (nb, reps))
         # the same on the host cores this one-GPU job may use (one QP per worker process)
         import subprocess
-        nw = max(1, min(16, os.cpu_count() or 1))
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except Exception:
+            avail = os.cpu_count() or 1
+        nw = max(1, min(64, avail))
         per_w = max(1, nb // nw)
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-batch-worker",
                                    "%d,%d,%g" % (w * per_w, (w + 1) * per_w, 5.0)], stdout=subprocess.PIPE, text=True)
