@@ -44,6 +44,7 @@
 #define LONG_ROW 512      // a row with at least this many entries gets a workgroup of its own (no LDS staging)
 #define HUGE_ROW 8192     // A rows this long are sliced over the whole grid in k_cg_A (partials finished by k_huge_reduce)
 #define MAX_PARTS 1024    // upper bound on workgroups that emit dot partials
+#define MAX_HUGE_FOLD 4   // up to this many huge rows are folded into k_cg_B (more: k_huge_reduce finishes them)
 #define INF_BOUND 1e26    // OSQP_INFTY * MIN_SCALING
 
 #define HIPCHK(call)                                                            \
@@ -80,11 +81,11 @@ struct DevMat {
 // kept as a plain dense b x b array (8 B per entry, no index) for the PCG operator kernel;
 // everything else of its rows (the A' part) stays in the sparse remainder matrix.
 #define DENSE_MAX 128          // lanes cover the block's columns in two 64-lane halves
-struct DenseBlk { int c0, b, off, pad; };   // first row/column, size, offset into val
+struct DenseBlk { int c0, b, off, pitch; };   // first row/column, size, offset into val, row pitch in doubles (even, zero padded)
 struct DenseP {
   int nblk;                  // dense blocks (0: feature off)
   const DenseBlk *blk;
-  const double *val;         // blocks back to back, each row-major (= column-major: symmetric)
+  const double *val;         // blocks back to back, each b rows of `pitch` doubles (zero padded; row-major = column-major: symmetric)
 };
 
 // Written by kernels only; read by the host between windows.
@@ -120,6 +121,8 @@ struct Ctx {             // static pointers / sizes, passed by value
   DevMat A, M;
   DevMat Mk;             // what k_cg_B streams: M itself, or its remainder when P has dense blocks
   DenseP dP;
+  int nh, hrow[MAX_HUGE_FOLD];     // huge rows of A folded into k_cg_B, and hcol: nh dense vectors hcol_k[j] = A(h_k, j)
+  const double *hcol;
   int gridA, gridM;      // launch grids (>=1) of row kernels over A / over M
   double *xy, *z, *zt, *va, *vb, *q, *l, *u, *rho, *rhoinv, *minv, *pdiag;
   double *r, *zz, *kp, *pt0, *pt1, *dxy, *dy, *cvec;
@@ -320,23 +323,25 @@ __device__ __forceinline__ double wave_row_dot(const DevMat &Mx, int ka, int kb,
 }
 
 // y = P_b x_b for one dense diagonal block by the whole workgroup.  P_b is symmetric, so
-// y_r = sum_j P_b[j][r] x_j: lane r walks DOWN column r while the wavefront reads row j
-// contiguously (1 KB, fully coalesced); x_j is uniform.  Wavefront w takes the rows
-// j = w, w+4, ...; every load of the block is issued before anything is consumed (<= 32 rows
-// per wavefront); the four partial vectors meet in LDS.  No index loads, no gathers.
+// y_r = sum_j P_b[j][r] x_j: a lane walks DOWN its columns while the wavefront reads row j contiguously.
+// Rows are stored with an even pitch (b rounded up; never a multiple of 32 doubles -- rows that all start on the
+// same 256-byte phase camp on a few memory channels: 19.5 instead of 12 us at pitch 128), so one wave instruction
+// fetches a whole row with 16-byte loads: lane l owns columns 2l and 2l+1 (measured against 8-byte loads at pitch b and
+// against v_mfma_f64_16x16x4_f64 in tools/mfma_dense_probe.hip: 7.65 vs 9.21 vs 9.83 us for the 400 blocks of
+// config 5, profiles/r02_mfma_dense_probe.json -- one right-hand side leaves the matrix cores nothing to do).
+// Wavefront w takes the rows j = w, w+4, ...; every load of the block is issued before anything is consumed
+// (<= 32 rows per wavefront); the four partial vectors meet in LDS.  No index loads, no gathers.
 // Returns y_r for r = threadIdx.x < b (0 otherwise); scratch: 5*DENSE_MAX doubles, x_b is left
 // in scratch[4*DENSE_MAX ...].  Ends with a barrier; the caller adds one before reusing scratch.
 __device__ __forceinline__ double dense_block_mv(const DenseP &dP, const DenseBlk d, const double *x, double *scratch) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const double *dv = dP.val + d.off;
-  const bool h0 = lane < d.b, h1 = lane + 64 < d.b;
-  double v0[DENSE_MAX / 4], v1[DENSE_MAX / 4];
+  const double2 *dv = reinterpret_cast<const double2 *>(dP.val + d.off);
+  const int hp = d.pitch >> 1;
+  double2 v[DENSE_MAX / 4];
 #pragma unroll
   for (int q = 0; q < DENSE_MAX / 4; ++q) {
     const int j = w + 4 * q;
-    const double *row = dv + (size_t)j * d.b;
-    v0[q] = (j < d.b && h0) ? row[lane] : 0.0;
-    v1[q] = (j < d.b && h1) ? row[lane + 64] : 0.0;
+    v[q] = (j < d.b && lane < hp) ? dv[(size_t)j * hp + lane] : double2{0.0, 0.0};
   }
   double *xl = scratch + 4 * DENSE_MAX;
   if ((int)threadIdx.x < DENSE_MAX) xl[threadIdx.x] = (int)threadIdx.x < d.b ? x[d.c0 + threadIdx.x] : 0.0;
@@ -345,9 +350,9 @@ __device__ __forceinline__ double dense_block_mv(const DenseP &dP, const DenseBl
 #pragma unroll
   for (int q = 0; q < DENSE_MAX / 4; ++q) {
     const double u = xl[min(w + 4 * q, DENSE_MAX - 1)];
-    a0 += v0[q] * u; a1 += v1[q] * u;
+    a0 += v[q].x * u; a1 += v[q].y * u;
   }
-  scratch[w * DENSE_MAX + lane] = a0; scratch[w * DENSE_MAX + 64 + lane] = a1;
+  scratch[w * DENSE_MAX + 2 * lane] = a0; scratch[w * DENSE_MAX + 2 * lane + 1] = a1;
   __syncthreads();
   const int r = threadIdx.x;
   return r < d.b ? (scratch[r] + scratch[DENSE_MAX + r]) + (scratch[2 * DENSE_MAX + r] + scratch[3 * DENSE_MAX + r]) : 0.0;
@@ -393,6 +398,7 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c, int bench) {
       const int j = d.c0 + threadIdx.x;
       double sB = 0.0;
       for (int k = Mm.rowptr[j]; k < Mm.rowptr[j + 1]; ++k) { const int cc = Mm.col[k]; const double v = Mm.val[k]; sA += v * c.vx[cc]; sB += v * c.vb[cc]; }
+      for (int k = 0; k < c.nh; ++k) { const double hc = c.hcol[(size_t)k * c.n + j]; sA += hc * c.vx[c.n + c.hrow[k]]; sB += hc * c.vb[c.n + c.hrow[k]]; }   // huge rows of A live outside Mk
       const double base = prm.use_cvec ? c.cvec[j] : (prm.sigma * c.xy[j] - c.q[j]);
       const double bj = base + sB;
       const double rj = bj - prm.sigma * c.vx[j] - sA;
@@ -423,6 +429,7 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c, int bench) {
         sB = row_sum_par(lprod + MAX_CHUNK, a0, a1, rlane, RL);
       }
       if (longrow ? threadIdx.x == 0 : rlane == 0) {
+        if (DENSE) for (int k = 0; k < c.nh; ++k) { const double hc = c.hcol[(size_t)k * c.n + j]; sA += hc * c.vx[c.n + c.hrow[k]]; sB += hc * c.vb[c.n + c.hrow[k]]; }
         const double base = prm.use_cvec ? c.cvec[j] : (prm.sigma * c.xy[j] - c.q[j]);
         const double bj = base + sB;
         const double rj = bj - prm.sigma * c.vx[j] - sA;
@@ -675,7 +682,7 @@ __global__ void __launch_bounds__(TB) k_huge_reduce(Ctx c, int flags) {
 
 // DENSE: P has dense diagonal blocks (their column walk keeps 64 loads per lane in flight and
 // needs ~190 registers; the plain instantiation stays lean for the sparse stream path).
-template <bool DENSE>
+template <bool DENSE, bool FOLD>
 __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   State *st = c.st;
   const bool bench = flags & 4;
@@ -693,10 +700,23 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   int rp0 = 0, rp1 = 0;
   G4 *gc = c.g4 + (size_t)(it & 1) * c.n;
   double pu = 0.0, pr = 0.0;           // u_j, r_j of this lane group's first row (off the tail's critical path)
+  // huge rows of A folded in: this thread's share of the k_cg_A partials of each (summed below), and the
+  // entries hcol_k[j] of this lane group's first row
+  double hs[MAX_HUGE_FOLD], ph[MAX_HUGE_FOLD], hrho[MAX_HUGE_FOLD];
+#pragma unroll
+  for (int k = 0; k < MAX_HUGE_FOLD; ++k) {
+    hs[k] = 0.0; ph[k] = 0.0; hrho[k] = 0.0;
+    if (FOLD && k < c.nh) {
+      hrho[k] = c.rho[c.hrow[k]];
+      for (int i = threadIdx.x; i < c.gridA; i += TB) hs[k] += c.part_h[(size_t)k * c.gridA + i];
+    }
+  }
   if (small) {
     if (b.r0 + rg < b.r1) {
       rp0 = c.Mk.rowptr[b.r0 + rg]; rp1 = c.Mk.rowptr[b.r0 + rg + 1];
       pu = c.ut[b.r0 + rg]; pr = gc[b.r0 + rg].r;
+#pragma unroll
+      for (int k = 0; k < MAX_HUGE_FOLD; ++k) if (FOLD && k < c.nh) ph[k] = c.hcol[(size_t)k * c.n + b.r0 + rg];
     }
     int ecol[EPT];
 #pragma unroll
@@ -712,6 +732,17 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   }
   if (!bench && (!run || done || skip_pre)) return;
   LDS_DECL(1);
+  double th[MAX_HUGE_FOLD];            // t_h = rho_h * (A u)_h of the folded huge rows, formed by every workgroup itself
+#pragma unroll
+  for (int k = 0; k < MAX_HUGE_FOLD; ++k) th[k] = (FOLD && k < c.nh) ? hrho[k] * block_sum(hs[k], red) : 0.0;
+  auto hterm = [&](int j, bool pref) {
+    double s = 0.0;
+    if (FOLD) {
+#pragma unroll
+      for (int k = 0; k < MAX_HUGE_FOLD; ++k) if (k < c.nh) s += (pref ? ph[k] : c.hcol[(size_t)k * c.n + j]) * th[k];
+    }
+    return s;
+  };
   double pg = 0, pd = 0, prr = 0;
   for (int bi = blockIdx.x; bi < c.Mk.nstream; bi += gridDim.x) {
     if (bi != (int)blockIdx.x) { b = c.Mk.blk[bi]; RL = lanes_for(b.r1 - b.r0); rg = threadIdx.x / RL; rlane = threadIdx.x % RL; }
@@ -729,7 +760,7 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
       if (rlane == 0) {
         const bool first = bi == (int)blockIdx.x && j == b.r0 + rg;
         const double uj = first ? pu : c.ut[j], rj = first ? pr : gc[j].r;
-        const double wj = acc + sigma * uj;
+        const double wj = (acc + sigma * uj) + hterm(j, first);
         gc[j].w = wj;
         pg += rj * uj; pd += wj * uj; prr += rj * rj;
       }
@@ -742,7 +773,7 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
     const double acc = wave_row_dot(c.Mk, lb.k0, lb.k1, [&](int cc) { return c.ut[cc]; });
     if ((threadIdx.x & 63) == 0) {
       const int j = lb.r0;
-      const double uj = c.ut[j], wj = acc + sigma * uj, rj = gc[j].r;
+      const double uj = c.ut[j], wj = (acc + sigma * uj) + hterm(j, false), rj = gc[j].r;
       gc[j].w = wj; pg += rj * uj; pd += wj * uj; prr += rj * rj;
     }
   }
@@ -754,7 +785,7 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
     if ((int)threadIdx.x < d.b) {
       const int jrow = d.c0 + threadIdx.x;
       for (int k = c.Mk.rowptr[jrow]; k < c.Mk.rowptr[jrow + 1]; ++k) acc += c.Mk.val[k] * c.ut[c.Mk.col[k]];   // A' part
-      const double uj = lprod[4 * DENSE_MAX + threadIdx.x], wj = acc + sigma * uj, rj = gc[jrow].r;
+      const double uj = lprod[4 * DENSE_MAX + threadIdx.x], wj = (acc + sigma * uj) + hterm(jrow, false), rj = gc[jrow].r;
       gc[jrow].w = wj; pg += rj * uj; pd += wj * uj; prr += rj * rj;
     }
     __syncthreads();
@@ -1219,6 +1250,9 @@ struct hipeng {
   hipStream_t stream = nullptr;
   HostMat A, M, Mr;                    // Mr: remainder of M outside P's dense blocks (empty: no dense blocks)
   std::vector<int> Mr_src, dP_src;     // slot in M of every Mr entry / dense entry (-1: structural zero)
+  std::vector<int> hrows, hcol_src;    // huge rows of A folded into k_cg_B; slot in M of hcol_k[j] (-1: zero)
+  int *d_hcol_src = nullptr;
+  double *d_hcol = nullptr;
   std::vector<DenseBlk> dP_blks;
   int *d_Mr_src = nullptr, *d_dP_src = nullptr;
   DenseBlk *d_dP_blks = nullptr;
@@ -1394,56 +1428,73 @@ static void build_M(hipeng *e, const csc *P, const csc *A) {
 // every path that changes M (scaling, osqp_update_P/A) only has to repack.
 static void build_dense(hipeng *e, const csc *P) {
   const int n = e->n;
-  if (const char *v = getenv("OSQP_AMD_DENSE_P")) if (atoi(v) == 0) return;
   if (n == 0) return;
+  std::vector<char> dense(n, 0);
+  const HostMat &M = e->M;
+  long long off = 0;
+  if (const char *v = getenv("OSQP_AMD_DENSE_P")) if (atoi(v) == 0) goto build_remainder;
+  {
   std::vector<int> lo(n), smin(n + 1, n);
   for (int j = 0; j < n; j++) {
     lo[j] = j;
     for (long long k = P->p[j]; k < P->p[j + 1]; k++) lo[j] = std::min(lo[j], (int)P->i[k]);
   }
   for (int j = n - 1; j >= 0; j--) smin[j] = std::min(smin[j + 1], lo[j]);
-  std::vector<char> dense(n, 0);
-  const HostMat &M = e->M;
-  long long off = 0;
   int s0 = 0;
   for (int j = 1; j <= n; j++) {
     if (j < n && smin[j] < j) continue;          // column j (or a later one) still reaches into the block
     const long long b = j - s0, nnz = P->p[j] - P->p[s0];
-    if (b >= 32 && b <= DENSE_MAX && 2 * nnz - b >= (b * b) / 2 && off + b * b < (1ll << 31)) {
+    long long pitch = (b + 1) & ~1ll;
+    if (pitch % 32 == 0 && pitch < DENSE_MAX) pitch += 2;
+    if (b >= 32 && b <= DENSE_MAX && 2 * nnz - b >= (b * b) / 2 && off + b * pitch < (1ll << 31)) {
       for (int i = s0; i < j; i++) dense[i] = 1;
-      e->dP_blks.push_back({s0, (int)b, (int)off, 0});
-      off += b * b;
+      e->dP_blks.push_back({s0, (int)b, (int)off, (int)pitch});
+      off += b * pitch;
     }
     s0 = j;
   }
-  if (e->dP_blks.empty()) return;
+  }
+build_remainder:
+  // Huge rows of A (sliced over the grid in k_cg_A): their entries leave the A' part of the matrix k_cg_B streams
+  // and become dense n-vectors hcol_k[j] = A(h_k, j); k_cg_B adds hcol_k[j] * t_{h_k} to row j with
+  // t_{h_k} = rho * (sum of the k_cg_A partials) formed by every workgroup itself -- no k_huge_reduce launch.
+  e->hrows.clear();
+  for (int q = e->A.nwave; q < (int)e->A.blk.size(); q++) e->hrows.push_back(e->A.blk[q].r0);
+  if ((int)e->hrows.size() > MAX_HUGE_FOLD) e->hrows.clear();        // many huge rows: keep the k_huge_reduce path
+  if (const char *v = getenv("OSQP_AMD_HFOLD")) if (atoi(v) == 0) e->hrows.clear();   // tuning experiments
+  if (e->dP_blks.empty() && e->hrows.empty()) return;
+  std::vector<int> hidx(e->m > 0 ? e->m : 1, -1);
+  for (size_t k = 0; k < e->hrows.size(); k++) hidx[e->hrows[k]] = (int)k;
+  e->hcol_src.assign(e->hrows.size() * (size_t)n, -1);
   e->dP_src.assign((size_t)off, -1);
   for (const DenseBlk &d : e->dP_blks)
     for (int i = d.c0; i < d.c0 + d.b; i++)
       for (int k = M.rowptr[i]; k < M.split[i]; k++)     // P part of the row: all inside the block
-        e->dP_src[(size_t)d.off + (size_t)(i - d.c0) * d.b + (M.col[k] - d.c0)] = k;
+        e->dP_src[(size_t)d.off + (size_t)(i - d.c0) * d.pitch + (M.col[k] - d.c0)] = k;
   HostMat &R = e->Mr;
   R.nrows = n; R.ncols = M.ncols;
   R.rowptr.assign(n + 1, 0);
-  for (int i = 0; i < n; i++) R.rowptr[i + 1] = R.rowptr[i] + (M.rowptr[i + 1] - (dense[i] ? M.split[i] : M.rowptr[i]));
-  R.col.resize(R.rowptr[n]); R.val.resize(R.rowptr[n]); e->Mr_src.resize(R.rowptr[n]);
+  R.col.clear(); R.val.clear(); e->Mr_src.clear();
   for (int i = 0; i < n; i++) {
-    int d = R.rowptr[i];
-    for (int k = dense[i] ? M.split[i] : M.rowptr[i]; k < M.rowptr[i + 1]; k++, d++) {
-      R.col[d] = M.col[k]; R.val[d] = M.val[k]; e->Mr_src[d] = k;
+    for (int k = dense[i] ? M.split[i] : M.rowptr[i]; k < M.rowptr[i + 1]; k++) {
+      if (k >= M.split[i] && hidx[M.col[k] - n] >= 0) { e->hcol_src[(size_t)hidx[M.col[k] - n] * n + i] = k; continue; }
+      R.col.push_back(M.col[k]); R.val.push_back(M.val[k]); e->Mr_src.push_back(k);
     }
+    R.rowptr[i + 1] = (int)R.col.size();
   }
-  build_blocks(R, pick_chunk(std::max(1, R.rowptr[n]), n), false, &dense);
+  build_blocks(R, pick_chunk(std::max(1, R.rowptr[n]), n), false, e->dP_blks.empty() ? nullptr : &dense);
 }
 
 // refresh the dense rows and the remainder matrix from the values of M (device side)
 static int repack_dense(hipeng *e) {
-  if (e->dP_blks.empty()) return 0;
-  const long long nr = (long long)e->Mr_src.size(), nd = (long long)e->dP_src.size();
+  if (e->dP_blks.empty() && e->hrows.empty()) return 0;
+  const long long nr = (long long)e->Mr_src.size(), nd = (long long)e->dP_src.size(), nh = (long long)e->hcol_src.size();
   if (nr) hipLaunchKernelGGL(k_repack, dim3((unsigned)std::min<long long>(4096, (nr + TB - 1) / TB)), dim3(TB), 0, e->stream,
                              e->M.d_val, e->d_Mr_src, e->Mr.d_val, nr);
-  hipLaunchKernelGGL(k_repack, dim3((unsigned)std::min<long long>(4096, (nd + TB - 1) / TB)), dim3(TB), 0, e->stream,
-                     e->M.d_val, e->d_dP_src, e->d_dP_val, nd);
+  if (nd) hipLaunchKernelGGL(k_repack, dim3((unsigned)std::min<long long>(4096, (nd + TB - 1) / TB)), dim3(TB), 0, e->stream,
+                             e->M.d_val, e->d_dP_src, e->d_dP_val, nd);
+  if (nh) hipLaunchKernelGGL(k_repack, dim3((unsigned)std::min<long long>(4096, (nh + TB - 1) / TB)), dim3(TB), 0, e->stream,
+                             e->M.d_val, e->d_hcol_src, e->d_hcol, nh);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1524,17 +1575,24 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   Ctx &c = e->c;
   c.n = n; c.m = m;
   c.A = dev_view(e->A); c.M = dev_view(e->M);
-  c.Mk = c.M; c.dP = DenseP{0, nullptr, nullptr};
-  if (!e->dP_blks.empty()) {
+  c.Mk = c.M; c.dP = DenseP{0, nullptr, nullptr}; c.nh = 0; c.hcol = nullptr;
+  if (!e->dP_blks.empty() || !e->hrows.empty()) {
     if (upload_mat(e, e->Mr)) return HIPENG_ERR_HIP;
     if (dev_alloc(e, &e->d_Mr_src, e->Mr_src.size()) || dev_alloc(e, &e->d_dP_src, e->dP_src.size()) ||
-        dev_alloc(e, &e->d_dP_blks, e->dP_blks.size()) || dev_alloc(e, &e->d_dP_val, e->dP_src.size())) return HIPENG_ERR_HIP;
+        dev_alloc(e, &e->d_dP_blks, e->dP_blks.size()) || dev_alloc(e, &e->d_dP_val, e->dP_src.size()) ||
+        dev_alloc(e, &e->d_hcol_src, e->hcol_src.size()) || dev_alloc(e, &e->d_hcol, e->hcol_src.size())) return HIPENG_ERR_HIP;
     if (!e->Mr_src.empty())
       HIPCHK(hipMemcpyAsync(e->d_Mr_src, e->Mr_src.data(), e->Mr_src.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->d_dP_src, e->dP_src.data(), e->dP_src.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->d_dP_blks, e->dP_blks.data(), e->dP_blks.size() * sizeof(DenseBlk), hipMemcpyHostToDevice, e->stream));
+    if (!e->dP_src.empty()) {
+      HIPCHK(hipMemcpyAsync(e->d_dP_src, e->dP_src.data(), e->dP_src.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(e->d_dP_blks, e->dP_blks.data(), e->dP_blks.size() * sizeof(DenseBlk), hipMemcpyHostToDevice, e->stream));
+    }
+    if (!e->hcol_src.empty())
+      HIPCHK(hipMemcpyAsync(e->d_hcol_src, e->hcol_src.data(), e->hcol_src.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
     c.Mk = dev_view(e->Mr);
-    c.dP = DenseP{(int)e->dP_blks.size(), e->d_dP_blks, e->d_dP_val};
+    if (!e->dP_blks.empty()) c.dP = DenseP{(int)e->dP_blks.size(), e->d_dP_blks, e->d_dP_val};
+    c.nh = (int)e->hrows.size(); c.hcol = e->d_hcol;
+    for (int k = 0; k < MAX_HUGE_FOLD; k++) c.hrow[k] = k < c.nh ? e->hrows[k] : 0;
     if (repack_dense(e)) return HIPENG_ERR_HIP;
   }
   {
@@ -1827,12 +1885,15 @@ static void launch_init(hipeng *e, int bench = 0) {
 
 static void launch_cg_A(hipeng *e, int it, int flags) {
   hipLaunchKernelGGL(k_cg_A, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, it, flags);
-  const int nhuge = e->c.A.nblk - e->c.A.nwave;
+  const int nhuge = e->c.nh ? 0 : e->c.A.nblk - e->c.A.nwave;   // folded into k_cg_B when c.nh > 0
   if (nhuge > 0 && !(flags & 16)) hipLaunchKernelGGL(k_huge_reduce, dim3(nhuge), dim3(TB), 0, e->stream, e->c, flags & 4);
 }
 static void launch_cg_B(hipeng *e, int it, int flags) {
-  if (e->c.dP.nblk) hipLaunchKernelGGL(k_cg_B<true>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
-  else hipLaunchKernelGGL(k_cg_B<false>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
+  const bool d = e->c.dP.nblk > 0, f = e->c.nh > 0;
+  if (d && f) hipLaunchKernelGGL((k_cg_B<true, true>), dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
+  else if (d) hipLaunchKernelGGL((k_cg_B<true, false>), dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
+  else if (f) hipLaunchKernelGGL((k_cg_B<false, true>), dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
+  else hipLaunchKernelGGL((k_cg_B<false, false>), dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
 }
 
 static void launch_pcg_iter(hipeng *e, int it, int flags) {
