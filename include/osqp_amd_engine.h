@@ -132,6 +132,10 @@ int hipeng_kkt_solve(hipeng *e, c_float *b);
  *         1: y = A' x  (mat_tpose_vec, lin_alg.c:273-322)
  *         2: y = P x   (mat_vec + mat_tpose_vec skip_diag on triu P) */
 int hipeng_spmv(hipeng *e, int which, const c_float *x, c_float *y);
+/* The same products on device pointers (d_x, d_y: n or m doubles in HBM), enqueued on the engine's stream
+ * without a sync -- hipeng_sync() orders them before other streams read d_y.  Building block of the
+ * row-partitioned multi-GPU variant. */
+int hipeng_spmv_dev(hipeng *e, int which, const c_float *d_x, c_float *d_y);
 /* Time `reps` back-to-back launches of one hot kernel on the engine stream with
  * HIP events; returns average microseconds per launch in *usec.
  * which = 0: K1 (A p), 1: K2 ([P|A'] apply), 2: K3 (vector update + dots). */

@@ -2153,6 +2153,31 @@ extern "C" int hipeng_spmv(hipeng *e, int which, const c_float *x, c_float *y) {
   return 0;
 }
 
+// Device-to-device SpMV with the engine's matrices (which as in hipeng_spmv), on the engine's stream, no sync:
+// the building block of the row-partitioned multi-GPU variant (osqp_amd/rowpart.py), whose vectors live in
+// torch tensors.  d_x / d_y are device pointers of n (A x: in, A' y / P x: out) or m doubles.
+extern "C" int hipeng_spmv_dev(hipeng *e, int which, const double *d_x, double *d_y) {
+  if (!e || !d_x || !d_y || which < 0 || which > 2) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  const int n = e->n, m = e->m;
+  if (which == 0) {
+    if (m > 0) hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, d_x, d_y, 0);
+  } else if (which == 1) {
+    // the fused row matrix reads y at column ids n + i: stage it behind n unused slots
+    double *in = e->c.pt0;
+    if (m > 0) HIPCHK(hipMemcpyAsync(in + n, d_x, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.M.nblk))), dim3(TB), 0, e->stream, e->c.M, (const double *)in, d_y, 2);
+  } else {
+    // k_spmv stages the products of whole rows of [P | A'] (the A' entries gather at column ids up to n + m - 1)
+    // before it sums the P part: the input must be n + m long, so x is staged too
+    double *in = e->c.pt0;
+    HIPCHK(hipMemcpyAsync(in, d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.M.nblk))), dim3(TB), 0, e->stream, e->c.M, (const double *)in, d_y, 1);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) {
   if (!e || !usec || reps <= 0 || which < 0 || which > 7) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
