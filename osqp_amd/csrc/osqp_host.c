@@ -920,6 +920,9 @@ static c_int patch(OSQPWorkspace *w, const c_float *Px, const c_int *Pi, c_int P
   upd_begin(w);
   if (doP && Pi && Pn > nnzP) { fprintf(stderr, "ERROR: new number of elements greater than elements in P\n"); return 1; }
   if (doA && Ai && An > nnzA) { fprintf(stderr, "ERROR: new number of elements greater than elements in A\n"); return doP ? 2 : 1; }
+  /* the reference trusts the index arrays; an index outside the matrix would write past its values */
+  if (doP && Pi) for (c_int k = 0; k < Pn; k++) if (Pi[k] < 0 || Pi[k] >= nnzP) { fprintf(stderr, "ERROR: index %lld outside P\n", (long long)Pi[k]); return 1; }
+  if (doA && Ai) for (c_int k = 0; k < An; k++) if (Ai[k] < 0 || Ai[k] >= nnzA) { fprintf(stderr, "ERROR: index %lld outside A\n", (long long)Ai[k]); return doP ? 2 : 1; }
   /* The reference unscales, patches and re-equilibrates from scratch (osqp.c:1046-1067).  Here
    * the unscaled problem is kept as given, patched, uploaded and re-equilibrated on the GPU. */
   csc *P = w->settings->scaling ? s->rawP : w->data->P;

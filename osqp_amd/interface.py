@@ -109,11 +109,17 @@ class SolverHandle:
         rc = 0
         if q is not None:
             q = abi.as_f64(q)
+            if q.shape != (self.n,):
+                raise ValueError("q must have %d entries" % self.n)
             rc |= self._api["update_lin_cost"](w, abi.fptr(q))
         if l is not None:
             l = np.maximum(abi.as_f64(l), -abi.OSQP_INFTY)
+            if l.shape != (self.m,):
+                raise ValueError("l must have %d entries" % self.m)
         if u is not None:
             u = np.minimum(abi.as_f64(u), abi.OSQP_INFTY)
+            if u.shape != (self.m,):
+                raise ValueError("u must have %d entries" % self.m)
         if l is not None and u is not None:
             rc |= self._api["update_bounds"](w, abi.fptr(l), abi.fptr(u))
         elif l is not None:
@@ -127,17 +133,34 @@ class SolverHandle:
             a = abi.as_i64(a)
             return a, abi.iptr(a)
 
+        def check(vals, ind, nnz, name):
+            # the C entry points trust their arguments like the reference's (osqp.c:1012-1169 reads nnz values when no
+            # index array is given and never range-checks the indices): refuse what would read or write out of bounds
+            if vals.ndim != 1:
+                raise ValueError("%sx must be a vector" % name)
+            if ind is None:
+                if vals.size != nnz:
+                    raise ValueError("%sx has %d values, %s has %d non-zeros (pass %sx_idx for a partial update)" % (name, vals.size, name, nnz, name))
+            else:
+                if ind.shape != vals.shape:
+                    raise ValueError("%sx and %sx_idx differ in length" % (name, name))
+                if ind.size and (ind.min() < 0 or ind.max() >= nnz):
+                    raise ValueError("%sx_idx out of range [0, %d)" % (name, nnz))
+
         if Px is not None and Ax is not None:
             Px = abi.as_f64(Px); Ax = abi.as_f64(Ax)
             pi, pip = idx(Px_idx); ai, aip = idx(Ax_idx)
+            check(Px, pi, self.nnzP, "P"); check(Ax, ai, self.nnzA, "A")
             rc |= self._api["update_P_A"](w, abi.fptr(Px), pip, len(Px), abi.fptr(Ax), aip, len(Ax))
         elif Px is not None:
             Px = abi.as_f64(Px)
             pi, pip = idx(Px_idx)
+            check(Px, pi, self.nnzP, "P")
             rc |= self._api["update_P"](w, abi.fptr(Px), pip, len(Px))
         elif Ax is not None:
             Ax = abi.as_f64(Ax)
             ai, aip = idx(Ax_idx)
+            check(Ax, ai, self.nnzA, "A")
             rc |= self._api["update_A"](w, abi.fptr(Ax), aip, len(Ax))
         return int(rc)
 
@@ -166,6 +189,8 @@ class SolverHandle:
 
     def warm_start(self, x=None, y=None):
         w = self._work
+        if (x is not None and np.shape(x) != (self.n,)) or (y is not None and np.shape(y) != (self.m,)):
+            raise ValueError("warm start vectors must have %d (x) and %d (y) entries" % (self.n, self.m))
         if x is not None and y is not None:
             x = abi.as_f64(x); y = abi.as_f64(y)
             return int(self._api["warm_start"](w, abi.fptr(x), abi.fptr(y)))

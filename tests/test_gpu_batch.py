@@ -144,3 +144,29 @@ def test_one_qp_per_stream_matches_sequential(gpu_lib):
     for a, b in zip(seq, par):
         assert a.info.iter == b.info.iter and a.info.status == b.info.status == "solved"
         assert np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y)
+
+
+def test_batch_members_above_128_variables_go_one_per_stream(gpu_lib, oracle_mod):
+    """n > 128 does not fit the register-tiled batch kernel: BatchOSQP then drives one single-QP engine per member
+    (one HIP stream each) behind the same interface; results per QP equal the oracle's."""
+    import osqp_amd
+    from osqp_amd.problems import random_sparse_qp
+    n, m, B = 150, 220, 5
+    base = random_sparse_qp(n, m, nnz_per_col=8, seed=31)
+    rng = np.random.default_rng(7)
+    Q = np.array([base["q"] + 0.3 * rng.standard_normal(n) for _ in range(B)])
+    L = np.array([base["l"] - rng.uniform(0, 0.2, m) for _ in range(B)]); U = np.array([base["u"] + rng.uniform(0, 0.2, m) for _ in range(B)])
+    bs = osqp_amd.BatchOSQP().setup(base["P"], base["A"], Q, L, U, eps_abs=1e-5, eps_rel=1e-5)
+    r = bs.solve()
+    assert r.x.shape == (B, n) and r.y.shape == (B, m)
+    for b in range(B):
+        ro = oracle_mod.OracleOSQP().setup(P=base["P"], q=Q[b], A=base["A"], l=L[b], u=U[b], eps_abs=1e-5, eps_rel=1e-5).solve()
+        assert r.status_val[b] == ro.info.status_val == 1 and r.iter[b] == ro.info.iter
+        assert np.abs(r.x[b] - ro.x).max() <= 1e-6 * max(1.0, np.abs(ro.x).max())
+        assert np.abs(r.y[b] - ro.y).max() <= 1e-6 * max(1.0, np.abs(ro.y).max())
+    assert bs.update(Q=Q[::-1].copy()) == 0
+    r2 = bs.solve()
+    ro = oracle_mod.OracleOSQP().setup(P=base["P"], q=Q[B - 1], A=base["A"], l=L[0], u=U[0], eps_abs=1e-5, eps_rel=1e-5).solve()
+    assert np.abs(r2.x[0] - ro.x).max() <= 1e-5 * max(1.0, np.abs(ro.x).max())
+    with pytest.raises(ValueError):
+        bs.update(Q=Q[:, :10])

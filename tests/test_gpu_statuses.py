@@ -201,3 +201,31 @@ def test_engine_options_are_per_workspace(gpu_lib):
     with pytest.raises(ValueError):
         s1.set_options(device=3)
     assert s1.solve().info.status == "solved" and s2.solve().info.status == "solved"
+
+
+def test_wrapper_rejects_out_of_bounds_updates(gpu_lib):
+    """The C entry points trust lengths and indices like the reference's (osqp.c:1012-1169); the Python wrapper
+    refuses what would read or write outside the matrices, and the C side refuses an out-of-range index."""
+    import ctypes as C
+    import osqp_amd
+    from osqp_amd import abi
+    from osqp_amd.problems import random_sparse_qp
+    pb = random_sparse_qp(60, 90, seed=2)
+    s = osqp_amd.OSQP().setup(**pb)
+    with pytest.raises(ValueError):
+        s.update(Px=np.ones(3))                                  # short value array without an index array
+    with pytest.raises(ValueError):
+        s.update(Ax=np.ones(2), Ax_idx=np.array([0, s.nnzA]))    # index past the end
+    with pytest.raises(ValueError):
+        s.update(Ax=np.ones(2), Ax_idx=np.array([0]))            # lengths differ
+    with pytest.raises(ValueError):
+        s.update(q=np.ones(59))
+    with pytest.raises(ValueError):
+        s.warm_start(x=np.ones(61))
+    bad = abi.as_i64(np.array([0, s.nnzP + 5])); v = abi.as_f64(np.ones(2))
+    assert s._api["update_P"](s._work, abi.fptr(v), abi.iptr(bad), 2) == 1
+    Pu = sparse.triu(pb["P"], format="csc"); Pu.sort_indices()
+    assert s.update(Px=1.01 * Pu.data[:2], Px_idx=np.array([0, 1])) == 0
+    assert s.solve().info.status == "solved"
+    with pytest.raises(ValueError):
+        osqp_amd.BatchOSQP().setup(pb["P"], pb["A"], np.zeros((2, 60)), np.ones((2, 90)), np.zeros((2, 90)))   # l > u
