@@ -110,7 +110,7 @@ struct State {
 
 struct Params {          // mutable scalars (host writes, kernels read)
   double sigma, alpha, eps_rel, eps_abs, cinv;
-  int    pcg_max_iter, use_cvec, has_scaling, k_expect;   // k_expect: PCG iterations the host expects per solve
+  int    pcg_max_iter, use_cvec, has_scaling, pad0;
   double ex_theta;         // extrapolation of the PCG start vector (0 = plain warm start)
   int    ex_h0, ex_h1;     // no extrapolation before iteration ex_h0 after a reset, half a step before ex_h1
   int    no_restart;       // setup-time convexity probe: any loss of positivity counts as negative curvature
@@ -139,7 +139,18 @@ struct Ctx {             // static pointers / sizes, passed by value
   double *part_h;        // huge A rows: [row][workgroup of k_cg_A] partial dots
   State  *st;
   const Params *prm;
+#ifdef OSQP_AMD_TIMELINE
+  unsigned long long *tl;  // make TIMELINE=1: [0] = count, then one word per kernel start: id << 56 | wall_clock64 (100 MHz)
+#endif
 };
+
+#ifdef OSQP_AMD_TIMELINE
+#define TL_CAP (1 << 20)
+#define TL_MARK(c, id) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long k_ = atomicAdd((c).tl, 1ull); \
+    if (k_ < TL_CAP - 2) (c).tl[1 + k_] = ((unsigned long long)(id) << 56) | (wall_clock64() & 0x00FFFFFFFFFFFFFFull); } } while (0)
+#else
+#define TL_MARK(c, id) do { } while (0)
+#endif
 
 enum {  // slots of Ctx::scal (max slots are bit patterns of non-negative doubles)
   SC_PRI_U, SC_PRI_S, SC_Z_U, SC_Z_S, SC_AX_U, SC_AX_S,
@@ -377,6 +388,7 @@ __device__ __forceinline__ double dense_block_mv(const DenseP &dP, const DenseBl
 template <bool DENSE>
 __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c, int bench) {
   State *st = c.st;
+  TL_MARK(c, 1);
   // A solve that ran out of unrolled PCG iterations (`stalled`, raised by k_admm_finalize) is continued by
   // this graph launch: no new right-hand side, the iteration kernels below pick the recurrences up where they
   // stopped (K is even, so the parity of every ping-pong buffer is preserved).
@@ -494,11 +506,15 @@ __device__ __forceinline__ CgStep cg_step(double rr, double gam, double del, dou
 }
 __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   State *st = c.st;
+  TL_MARK(c, 2);
   const bool bench = flags & 4, upd_only = flags & 16, apply_only = flags & 32;
   const bool pre = (flags & 8) || apply_only;   // gather u directly (no recompute)
-  // unrolled iterations beyond the expected count are almost always no-ops: look at the
-  // flags first there instead of prefetching speculatively
-  if (!bench && it > c.prm->k_expect && (!st->run || st->done)) return;
+  // An unrolled slot whose turn never comes costs a whole kernel if it prefetches its operands before it
+  // looks at the flags (the wave cannot retire before its loads land: 4-6 us instead of 1.4, measured with
+  // `make TIMELINE=1`).  Slots at or beyond the PREVIOUS solve's iteration count (left in the state by
+  // k_admm_finalize, same cache line as the flags) therefore look first; so does a graph that continues a
+  // stalled solve.  The count moves by about one between consecutive ADMM iterations.
+  if (!bench && (it >= st->iters_last || st->stalled) && (!st->run || st->done)) return;
   // ---- issue every independent load before looking at the flags ----
   const int stalled = st->stalled, run = st->run, done = st->done, neg = st->neg_curv;
   const int iters_prev = st->iters[(it + 1) & 1];
@@ -685,8 +701,9 @@ __global__ void __launch_bounds__(TB) k_huge_reduce(Ctx c, int flags) {
 template <bool DENSE, bool FOLD>
 __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   State *st = c.st;
+  TL_MARK(c, 3);
   const bool bench = flags & 4;
-  if (!bench && it > c.prm->k_expect && (!st->run || st->done)) return;
+  if (!bench && (it >= st->iters_last || st->stalled) && (!st->run || st->done)) return;     // see k_cg_A
   const int run = st->run, done = st->done, skip_pre = it < 0 && st->stalled;
   const double sigma = c.prm->sigma;
   const bool has_blk = (int)blockIdx.x < c.Mk.nstream;
@@ -794,6 +811,7 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   if (threadIdx.x == 0) { c.part_gam[blockIdx.x] = pg; c.part_del[blockIdx.x] = pd; c.part_rr[blockIdx.x] = prr; }
 }
 
+
 // Slices of A_i . x for the huge rows of A (every workgroup one strided slice, one partial
 // each); the consumer adds the partials in a fixed order.  Launched only when A has huge rows.
 __global__ void __launch_bounds__(TB) k_huge_dot(Ctx c, const double *x, int always) {
@@ -830,6 +848,7 @@ __device__ __forceinline__ double huge_row_sum(const Ctx &c, int bi, double *red
 // iterations the iteration is left untouched and `stalled` is raised.
 __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
   State *st = c.st;
+  TL_MARK(c, 4);
   if (!st->run) return;
   LDS_DECL(1);
   const Params prm = *c.prm;
@@ -1608,6 +1627,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   DA(dxy, n + m); DA(dy, m); DA(cvec, n);
   DA(pdir, n); DA(ut, n + m); DA(g4, 2 * n);
   DA(vx, n + m); DA(vold, n + m);
+
   DA(D, n); DA(Dinv, n); DA(E, m); DA(Einv, m);
   const int np = std::max(std::max(c.gridM, c.gridA), 2048);   // also scratch for the scaling kernels
   DA(part_rz, np); DA(part_rr, np); DA(part_bb, np); DA(part_pkp, np);
@@ -1615,6 +1635,9 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   DA(scal, SC_COUNT * 16);
   DA(part_h, (size_t)std::max(1, c.A.nblk - c.A.nwave) * c.gridA);
   DA(st, 1);
+#ifdef OSQP_AMD_TIMELINE
+  DA(tl, TL_CAP);
+#endif
 #undef DA
   {
     c.init_r = &c.g4[n].r; c.init_stride = 4; c.init_z = c.ut; c.fin_rr = c.part_rr; c.fin_cnt = c.gridM;
@@ -1626,13 +1649,13 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   e->prm.sigma = prm->sigma; e->prm.alpha = prm->alpha;
   e->prm.eps_rel = prm->pcg_eps_rel; e->prm.eps_abs = prm->pcg_eps_abs;
   e->prm.pcg_max_iter = (int)prm->pcg_max_iter; e->prm.cinv = 1.0;
-  e->prm.use_cvec = 0; e->prm.has_scaling = 0; e->prm.k_expect = 1 << 30;
+  e->prm.use_cvec = 0; e->prm.has_scaling = 0; e->prm.pad0 = 0;
   e->prm.ex_theta = 1.0; e->prm.ex_h0 = 5; e->prm.ex_h1 = 12; e->prm.no_restart = 0;
   if (const char *x = getenv("OSQP_AMD_EXTRAP_SCHED")) sscanf(x, "%d,%d", &e->prm.ex_h0, &e->prm.ex_h1);
   if (const char *x = getenv("OSQP_AMD_EXTRAP")) e->prm.ex_theta = atof(x);
   if (e->prm.ex_theta == 0.0) c.vx = c.va;   // plain warm start
   e->ex_theta0 = e->prm.ex_theta;
-  if (prm->pcg_eps_rel < 1e-10) e->prm.ex_theta = 0.0;
+  if (prm->pcg_eps_rel < 0.5e-12) e->prm.ex_theta = 0.0;
   if (push_params(e)) return HIPENG_ERR_HIP;
   if (upload_vec(e, c.q, q, n) || upload_vec(e, c.l, l, m) || upload_vec(e, c.u, u, m) ||
       upload_vec(e, c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
@@ -1673,8 +1696,8 @@ extern "C" int hipeng_set_params(hipeng *e, const hipeng_params *prm) {
   // Extrapolated start vectors pay while PCG does real work.  When the caller asks for more
   // than the default accuracy (tight eps_abs/eps_rel tighten pcg_eps_rel, see osqp_solve) every
   // digit of the solve counts and the residual-based stop from a closer start leaves a
-  // slightly larger error: plain warm start there.
-  e->prm.ex_theta = prm->pcg_eps_rel >= 1e-10 ? e->ex_theta0 : 0.0;
+  // slightly larger error: plain warm start below 1e-12 (the stop equality-row problems get by default).
+  e->prm.ex_theta = prm->pcg_eps_rel >= 0.5e-12 ? e->ex_theta0 : 0.0;
   if (push_params(e)) return HIPENG_ERR_HIP;
   if (sigma_changed) refresh_operator(e);
   return 0;
@@ -2006,10 +2029,6 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     e->K = next_K(std::max(2, base + khead), cap);
     e->calibrated = true;
     if (remaining > 0) HIPCHK(hipMemsetAsync(&e->c.st->iters_max, 0, sizeof(int), e->stream));
-    if (std::abs(e->prm.k_expect - base) > 1) {
-      e->prm.k_expect = base;
-      if (push_params(e)) return HIPENG_ERR_HIP;
-    }
     if (++guard > 1000000) { fprintf(stderr, "osqp_amd: the ADMM run loop did not terminate\n"); return HIPENG_ERR_HIP; }
   }
   e->admm_total = s.admm_done;
@@ -2184,6 +2203,7 @@ extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) 
   auto one = [&](int it) {
     if (which == 5) { launch_init(e, 1); return; }   // first kernel of an ADMM iteration
     if (which == 6) { launch_pcg_iter(e, it, 4); return; }   // one whole PCG iteration (all its launches, in loop order)
+
     if (which == 7) { hipLaunchKernelGGL(k_fill, dim3(1), dim3(TB), 0, e->stream, e->c.cvec, 0.0, 0); return; }   // empty dependent launch
     if (which == 0) launch_cg_A(e, it, 4);
     else if (which == 3) launch_cg_A(e, it, 4 | 16);
@@ -2210,6 +2230,20 @@ extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) 
   *usec = 1e3 * (double)ms / reps;
   return 0;
 }
+
+#ifdef OSQP_AMD_TIMELINE
+// make TIMELINE=1 builds only: copy out (and reset) the kernel start marks; returns their number
+extern "C" long long hipeng_timeline(hipeng *e, unsigned long long *out, long long cap) {
+  if (!e || !out) return -1;
+  if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) return -1;
+  unsigned long long cnt = 0;
+  if (hipMemcpy(&cnt, e->c.tl, sizeof cnt, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  const long long k = (long long)std::min<unsigned long long>(std::min<unsigned long long>(cnt, TL_CAP - 2), (unsigned long long)cap);
+  if (k > 0 && hipMemcpy(out, e->c.tl + 1, (size_t)k * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemset(e->c.tl, 0, sizeof(unsigned long long)) != hipSuccess) return -1;
+  return k;
+}
+#endif
 
 // 1 if the vector update and the operator apply of k_cg_A run as two launches (A dominated by long rows)
 extern "C" int hipeng_is_split(hipeng *e) { return e && e->split ? 1 : 0; }

@@ -22,3 +22,24 @@ print("iters %d in %.3f ms -> %.1f us per ADMM iteration; %.2f PCG iterations ea
 print("kernel periods: A %.2f us, B %.2f us, init %.2f us -> PCG kernels alone %.1f us per ADMM iteration" % (
     us[0].value, us[1].value, us[2].value, (pcg / r.info.iter + 1) * (us[0].value + us[1].value)))
 print("one PCG iteration in loop order (A then B): %.2f us; empty dependent launch: %.2f us" % (us[3].value, us[4].value))
+
+if hasattr(L, "hipeng_timeline"):      # make TIMELINE=1 build: where the time of one ADMM iteration goes
+    L.hipeng_timeline.restype = C.c_longlong; L.hipeng_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
+    buf = np.zeros(1 << 20, dtype=np.uint64)
+    L.hipeng_timeline(s.engine(), buf.ctypes.data, buf.size)          # drop what the runs above left
+    r = s.solve()
+    k = L.hipeng_timeline(s.engine(), buf.ctypes.data, buf.size)
+    ids = (buf[:k] >> np.uint64(56)).astype(int); ts = (buf[:k] & np.uint64((1 << 56) - 1)).astype(np.int64) * 10e-3   # us
+    order = np.argsort(ts, kind="stable"); ids, ts = ids[order], ts[order]
+    per = np.diff(ts)
+    names = {1: "k_pcg_init", 2: "k_cg_A", 3: "k_cg_B", 4: "k_admm_finalize"}
+    print("timeline: %d kernel starts over %.1f us; %d ADMM iterations" % (k, ts[-1] - ts[0], r.info.iter))
+    tot = 0.0
+    for i in (1, 2, 3, 4):
+        p = per[ids[:-1] == i]
+        if p.size == 0: continue
+        act = p[p >= 2.6]; noop = p[p < 2.6]
+        print("  %-16s %6d launches: active %6d mean %5.2f us (sum %8.1f) | early-exit %6d mean %5.2f us (sum %8.1f) | > 30 us: %d (sum %.1f)" % (
+            names[i], p.size, act.size, act[act < 30].mean() if (act < 30).any() else 0, act[act < 30].sum(), noop.size, noop.mean() if noop.size else 0, noop.sum(),
+            (p >= 30).sum(), p[p >= 30].sum()))
+    print("  per ADMM iteration: %.1f us total" % ((ts[-1] - ts[0]) / r.info.iter))
