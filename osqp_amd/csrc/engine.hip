@@ -98,6 +98,7 @@ struct State {
   int    neg_curv_seen;
   int    iters_last;
   int    iters_max;
+  int    iters_min;        // smallest PCG iteration count of a solve since the host last reset it
   int    forced;
   long long iters_total;
   long long admm_done;
@@ -513,8 +514,10 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   // looks at the flags (the wave cannot retire before its loads land: 4-6 us instead of 1.4, measured with
   // `make TIMELINE=1`).  Slots at or beyond the PREVIOUS solve's iteration count (left in the state by
   // k_admm_finalize, same cache line as the flags) therefore look first; so does a graph that continues a
-  // stalled solve.  The count moves by about one between consecutive ADMM iterations.
-  if (!bench && (it >= st->iters_last || st->stalled) && (!st->run || st->done)) return;
+  // stalled solve.  The count moves by about one between consecutive ADMM iterations.  Looking first costs a
+  // dependent load before anything else is issued, so slots below the smallest count of the last window
+  // (baked into the graph node: flags >> 8) skip it.
+  if (!bench && it >= (flags >> 8) && (it >= st->iters_last || st->stalled) && (!st->run || st->done)) return;
   // ---- issue every independent load before looking at the flags ----
   const int stalled = st->stalled, run = st->run, done = st->done, neg = st->neg_curv;
   const int iters_prev = st->iters[(it + 1) & 1];
@@ -703,7 +706,7 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   State *st = c.st;
   TL_MARK(c, 3);
   const bool bench = flags & 4;
-  if (!bench && (it >= st->iters_last || st->stalled) && (!st->run || st->done)) return;     // see k_cg_A
+  if (!bench && it >= (flags >> 8) && (it >= st->iters_last || st->stalled) && (!st->run || st->done)) return;     // see k_cg_A
   const int run = st->run, done = st->done, skip_pre = it < 0 && st->stalled;
   const double sigma = c.prm->sigma;
   const bool has_blk = (int)blockIdx.x < c.Mk.nstream;
@@ -867,6 +870,7 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
     st->iters_last = iters;
     st->iters_total += iters;
     if (iters > st->iters_max) st->iters_max = iters;
+    if (iters < st->iters_min) st->iters_min = iters;
     if (!conv) st->forced += 1;
     if (st->neg_curv) st->neg_curv_seen += 1;
   }
@@ -1286,6 +1290,7 @@ struct hipeng {
   std::vector<void *> allocs;
   std::map<int, hipGraphExec_t> graphs;
   int K = 8;
+  int spec_lo = 0;           // unrolled slots below this prefetch without a look at the flags (smallest count of the last window)
   bool split = false;     // large A: vector update and operator apply as two launches (plain 8-byte gathers)
   int rlA = 8, rlM = 8;   // lanes per row segment in the PCG kernels
   bool calibrated = false;
@@ -1797,7 +1802,7 @@ extern "C" int hipeng_upload_rho(hipeng *e, const c_float *rho_vec) {
   refresh_operator(e);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));
-  e->calibrated = false;   // the PCG iteration count usually jumps after a rho change
+  e->calibrated = false; e->spec_lo = 0;   // the PCG iteration count usually jumps after a rho change
   return 0;
 }
 
@@ -1859,7 +1864,7 @@ extern "C" int hipeng_cold_start(hipeng *e) {
   HIPCHK(hipMemsetAsync(e->c.vb, 0, std::max<size_t>(nm, 8), e->stream));
   HIPCHK(hipMemsetAsync(e->c.z, 0, std::max<size_t>(e->m, 1) * sizeof(double), e->stream));
   HIPCHK(hipMemsetAsync(e->c.zt, 0, std::max<size_t>(e->m, 1) * sizeof(double), e->stream));
-  e->calibrated = false;   // the first solve from zero needs far more PCG iterations than the steady state
+  e->calibrated = false; e->spec_lo = 0;   // the first solve from zero needs far more PCG iterations than the steady state
   e->start_dirty = true;
   return 0;
 }
@@ -1919,10 +1924,11 @@ static void launch_cg_B(hipeng *e, int it, int flags) {
   else hipLaunchKernelGGL((k_cg_B<false, false>), dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, it, flags);
 }
 
-static void launch_pcg_iter(hipeng *e, int it, int flags) {
-  if (e->split) { launch_cg_A(e, it, (flags & 4) | 16); launch_cg_A(e, it, (flags & 4) | 32); }
-  else launch_cg_A(e, it, flags & 4);
-  launch_cg_B(e, it, flags & 4);
+static void launch_pcg_iter(hipeng *e, int it, int flags, int spec_lo = 0) {
+  const int hi = spec_lo << 8;     // slots below spec_lo prefetch without looking at the flags first (k_cg_A)
+  if (e->split) { launch_cg_A(e, it, (flags & 4) | 16 | hi); launch_cg_A(e, it, (flags & 4) | 32 | hi); }
+  else launch_cg_A(e, it, (flags & 4) | hi);
+  launch_cg_B(e, it, (flags & 4) | hi);
 }
 
 // One ADMM iteration as a graph: k_pcg_init, the operator on u0 ("pre" pass), K unrolled PCG
@@ -1930,8 +1936,8 @@ static void launch_pcg_iter(hipeng *e, int it, int flags) {
 // launch of the same graph continues the solve (its init and pre pass return at once).
 // R such segments back to back form one graph (a graph launch has a fixed cost of its own on the GPU
 // timeline); a segment whose predecessor stalled continues it, segments beyond admm_target return at once.
-static int get_graph(hipeng *e, int K, int R, hipGraphExec_t *out) {
-  const int key = K * 64 + R;
+static int get_graph(hipeng *e, int K, int R, int spec_lo, hipGraphExec_t *out) {
+  const int key = (K * 64 + R) * 1024 + spec_lo;
   auto f = e->graphs.find(key);
   if (f != e->graphs.end()) { *out = f->second; return 0; }
   hipGraph_t g = nullptr;
@@ -1941,7 +1947,7 @@ static int get_graph(hipeng *e, int K, int R, hipGraphExec_t *out) {
   for (int seg = 0; seg < R; seg++) {
     launch_init(e);
     launch_cg_A(e, -1, 8); launch_cg_B(e, -1, 0);   // operator apply on u0 (+ first convergence test), then w0 and the first dots
-    for (int it = 0; it < K; it++) launch_pcg_iter(e, it, 0);
+    for (int it = 0; it < K; it++) launch_pcg_iter(e, it, 0, spec_lo);
     if (e->c.A.nblk > e->c.A.nwave) hipLaunchKernelGGL(k_huge_dot, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, (const double *)nullptr, 0);
     hipLaunchKernelGGL(k_admm_finalize, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c);
   }
@@ -1993,6 +1999,7 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   *e->h_target = target;
   HIPCHK(hipMemcpyAsync(&e->c.st->admm_target, e->h_target, sizeof(long long), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemsetAsync(&e->c.st->iters_max, 0, sizeof(int), e->stream));
+  HIPCHK(hipMemsetAsync(&e->c.st->iters_min, 0x7f, sizeof(int), e->stream));
   if (e->start_dirty) { if (reset_start(e)) return HIPENG_ERR_HIP; e->start_dirty = false; }
   long long remaining = count;
   const int cap = std::max(2, e->prm.pcg_max_iter);
@@ -2009,8 +2016,8 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     // (graphs with many nodes only when the unroll is short: keeps instantiation cheap for long PCG runs)
     const int R = e->K <= 48 ? segs : 1;
     hipGraphExec_t gR = nullptr, g1 = nullptr;
-    if (burst >= R && R > 1 && get_graph(e, e->K, R, &gR)) return HIPENG_ERR_HIP;
-    if ((!gR || burst % R) && get_graph(e, e->K, 1, &g1)) return HIPENG_ERR_HIP;
+    if (burst >= R && R > 1 && get_graph(e, e->K, R, e->spec_lo, &gR)) return HIPENG_ERR_HIP;
+    if ((!gR || burst % R) && get_graph(e, e->K, 1, e->spec_lo, &g1)) return HIPENG_ERR_HIP;
     long long left = burst;
     for (; gR && left >= R; left -= R) { HIPCHK(hipGraphLaunch(gR, e->stream)); e->stats.graph_launches += 1; }
     for (; left > 0; left--) { HIPCHK(hipGraphLaunch(g1, e->stream)); e->stats.graph_launches += 1; }
@@ -2027,8 +2034,13 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     int base = e->calibrated ? std::max(s.iters_max, in_flight) : std::max(s.iters_last, in_flight);
     if (stalls && base <= e->K) base = e->K + 2;
     e->K = next_K(std::max(2, base + khead), cap);
+    // slots every solve of the last window needed (two below its smallest count, in steps of 4: few distinct graphs)
+    e->spec_lo = (e->calibrated && s.iters_min < (1 << 20) && !stalls) ? std::min(1000, std::max(0, ((s.iters_min - 2) / 4) * 4)) : 0;
     e->calibrated = true;
-    if (remaining > 0) HIPCHK(hipMemsetAsync(&e->c.st->iters_max, 0, sizeof(int), e->stream));
+    if (remaining > 0) {
+      HIPCHK(hipMemsetAsync(&e->c.st->iters_max, 0, sizeof(int), e->stream));
+      HIPCHK(hipMemsetAsync(&e->c.st->iters_min, 0x7f, sizeof(int), e->stream));
+    }
     if (++guard > 1000000) { fprintf(stderr, "osqp_amd: the ADMM run loop did not terminate\n"); return HIPENG_ERR_HIP; }
   }
   e->admm_total = s.admm_done;
@@ -2052,7 +2064,7 @@ extern "C" int hipeng_reset_stats(hipeng *e) {
   e->stats = hipeng_stats{};
   e->stats.kernels_per_pcg_iter = 2;
   e->calibrated = false;
-  e->K = 8;
+  e->K = 8; e->spec_lo = 0;
   return 0;
 }
 
