@@ -37,6 +37,7 @@
 #include <vector>
 #include <map>
 #include <algorithm>
+#include <mutex>
 #include "../../include/osqp_amd_engine.h"
 
 #define TB 256            // threads per workgroup (4 wavefronts of 64)
@@ -107,6 +108,8 @@ struct State {
   double gam[2], alp[2];   // Chronopoulos-Gear scalars (ping-pong on parity)
   int    hist_r;           // ADMM iterations since the PCG start vector history was reset (k_pcg_init counts)
   long long admm_target;   // k_pcg_init starts no new ADMM iteration once admm_done has reached this
+  unsigned res_epoch;      // resident PCG: tag of the last exchange of the previous launch
+  int    res_fail;         // resident PCG: a wait timed out (workgroups not co-resident); the host falls back to the launch-per-step path
 };
 
 struct Params {          // mutable scalars (host writes, kernels read)
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c, int bench) {
   // this graph launch: no new right-hand side, the iteration kernels below pick the recurrences up where they
   // stopped (K is even, so the parity of every ping-pong buffer is preserved).
   if (!bench) {
-    if (st->stalled) return;
+    if (st->stalled || st->res_fail) return;
     if (st->admm_done >= st->admm_target) { if (blockIdx.x == 0 && threadIdx.x == 0) st->run = 0; return; }
   }
   LDS_DECL(2);
@@ -852,7 +855,7 @@ __device__ __forceinline__ double huge_row_sum(const Ctx &c, int bi, double *red
 __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
   State *st = c.st;
   TL_MARK(c, 4);
-  if (!st->run) return;
+  if (!st->run || st->res_fail) return;
   LDS_DECL(1);
   const Params prm = *c.prm;
   double rr[1];
@@ -920,6 +923,277 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
       }
     }
     __syncthreads();
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// Resident PCG: the whole linear solve of one ADMM iteration in ONE launch.
+//
+// For problems whose reduced matrix K = P + sigma I + A' diag(rho) A fits the chip's register files
+// (n <= 16384, nnz(K) <= 256 workgroups x 512 threads x 64 entries) every workgroup keeps a block of
+// rows of K -- values and 16-bit column ids -- in registers for the whole solve, one workgroup per CU.
+// A Chronopoulos-Gear iteration then needs two exchanges between the workgroups instead of two kernel
+// boundaries with their re-streaming of A and M:
+//   (1) the vector u = Minv r: every workgroup stores its rows write-through (sc1), drains, raises its
+//       flag; one wavefront polls the 256 flags; then all wavefronts read the n doubles into LDS with
+//       L1-bypassing (sc1) loads -- no fence (MI355X_MICROARCH.md, visibility: the flag/sc1 row);
+//   (2) the three dot partials per workgroup as 16-byte {value, tag} granules: the data is the flag.
+// Measured in tools/exchange_probe.hip: 4.6 us for (1) at n = 10000 against 12.2 us for a k_cg_A/k_cg_B pair.
+// The recurrences, the stop rule and the scalars are those of k_cg_A / k_cg_B (cg_step); the operator is the
+// explicit K (k_form_K re-forms its values whenever rho, sigma or the matrices change).
+// Every wait is bounded in time: if the grid is not co-resident (another process or stream holds CUs) the
+// launch gives up, sets State::res_fail, and the host continues with the launch-per-step kernels.
+// ---------------------------------------------------------------------------
+#define RES_TB 512
+#define RES_MAXROWS 64
+#define RES_MAXN (RES_MAXROWS * 256)
+#define RES_MAXLD (RES_MAXN / 2 / RES_TB)   // 16-byte loads per thread that sweep the exchanged vector
+#define RES_WAIT_TICKS 2000000LL      // 20 ms of the 100 MHz wall clock per wait
+#define AUX_SC1 16
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+struct ResWG { int r0, nr, cnt, pad; };   // first row, rows (<= RES_MAXROWS), entries of K
+struct ResCtx {
+  int nwg, E, npad;                  // workgroups, entries per thread, n rounded up to even
+  const ResWG *wg;
+  double *val;                       // [nwg][E][RES_TB]: entry t*E + k of the workgroup's row-major list at (k, t)
+  const unsigned short *col;         // same layout
+  const unsigned char *rowl;         // same layout: local row of the entry
+  const int *psrc;                   // same layout: slot in M of P(i,j), -1 if none
+  const unsigned long long *brk;     // [nwg][RES_TB]: bit k set = entry k ends a row segment of this thread
+  const unsigned short *slot0;       // [nwg][RES_TB]: first segment slot of the thread
+  const unsigned short *segrow;      // [nwg][RES_MAXROWS + 1]: first segment slot of each local row
+  double *ubuf;                      // 2 x npad doubles (parity of the tag)
+  unsigned *flags;                   // nwg x 16 words (one 64-byte line each)
+  double *sbuf;                      // 2 x nwg x 4 granules {double, tag}
+};
+
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const void *p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+// K values in the resident layout.  K_ij = P_ij + sigma [i == j] + sum_k rho_k A_ki A_kj: the sum runs over the rows k
+// that columns i and j of A share (two sorted lists: the A' parts of rows i and j of M), in ascending k -- the same
+// order for (i,j) and (j,i), so K is symmetric to the bit.
+__global__ void __launch_bounds__(TB) k_form_K(Ctx c, ResCtx rc) {
+  const double sigma = c.prm->sigma;
+  const size_t total = (size_t)rc.nwg * rc.E * RES_TB;
+  for (size_t sl = (size_t)blockIdx.x * TB + threadIdx.x; sl < total; sl += (size_t)gridDim.x * TB) {
+    const int t = (int)(sl % RES_TB), k = (int)((sl / RES_TB) % rc.E), g = (int)(sl / ((size_t)RES_TB * rc.E));
+    const ResWG w = rc.wg[g];
+    double v = 0.0;
+    if (t * rc.E + k < w.cnt) {
+      const int i = w.r0 + rc.rowl[sl], j = rc.col[sl], ps = rc.psrc[sl];
+      v = (ps >= 0 ? c.M.val[ps] : 0.0) + (i == j ? sigma : 0.0);
+      int a = c.M.split[i], b = c.M.split[j];
+      const int ae = c.M.rowptr[i + 1], be = c.M.rowptr[j + 1];
+      while (a < ae && b < be) {
+        const int ka = c.M.col[a], kb = c.M.col[b];
+        if (ka == kb) { v += c.rho[ka - c.n] * (c.M.val[a] * c.M.val[b]); ++a; ++b; }
+        else if (ka < kb) ++a; else ++b;
+      }
+    }
+    rc.val[sl] = v;
+  }
+}
+
+template <int E>
+__global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
+  extern __shared__ __attribute__((aligned(16))) double rlds[];
+  State *st = c.st;
+  TL_MARK(c, 5);
+  if (st->stalled || !st->run || st->res_fail) return;
+  double *uv = rlds;                              // npad doubles: the exchanged vector
+  double *seg = uv + rc.npad;                     // RES_TB + RES_MAXROWS row-segment sums
+  double *sc = seg + RES_TB + RES_MAXROWS;        // 4 doubles: gamma, delta, rr, fail word
+#ifdef OSQP_AMD_TIMELINE
+  long long *tls = reinterpret_cast<long long *>(sc + 8);   // phase stamps of the first 64 iterations (workgroup 0)
+#define RTL(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && nx <= 64) tls[(nx - 1) * 5 + (k)] = wall_clock64(); } while (0)
+#else
+#define RTL(k) do { } while (0)
+#endif
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int nwg = rc.nwg, npad = rc.npad;
+  const ResWG w = rc.wg[g];
+  const Params prm = *c.prm;
+  const unsigned ep0 = st->res_epoch;
+  // ---- own slice of K into registers (issued first: in flight under everything below) ----
+  double kv[E]; unsigned short kc[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const size_t idx = ((size_t)g * E + k) * RES_TB + t;
+    kv[k] = rc.val[idx]; kc[k] = rc.col[idx];
+  }
+  const unsigned long long brk = rc.brk[(size_t)g * RES_TB + t];
+  const int slot0 = rc.slot0[(size_t)g * RES_TB + t];
+  int sr0 = 0, sr1 = 0;
+  // ---- start-up scalars: ||r0||^2, ||b||^2 from k_pcg_init's partials (every wavefront, same order) ----
+  double rr0 = 0.0, bb = 0.0;
+  for (int i = lane; i < c.gridM; i += 64) { rr0 += c.part_rr[i]; bb += c.part_bb[i]; }
+  rr0 = wave_sum(rr0); bb = wave_sum(bb);
+  const double tol2 = fmax(prm.eps_rel * prm.eps_rel * bb, prm.eps_abs * prm.eps_abs);
+  if (rr0 <= tol2) {
+    if (g == 0 && t == 0) { st->done = 1; st->tol2 = tol2; }
+    return;
+  }
+  // rows of this workgroup live in the lanes of wavefront 0
+  const bool own = wv == 0 && lane < w.nr;
+  const int j = w.r0 + lane;
+  double r_ = 0, u_ = 0, w_ = 0, p_ = 0, s_ = 0, x_ = 0, mi = 0;
+  if (own) {
+    r_ = c.init_r[(size_t)j * c.init_stride]; u_ = c.init_z[j]; x_ = c.vx[j]; mi = c.minv[j];
+    sr0 = rc.segrow[(size_t)g * (RES_MAXROWS + 1) + lane]; sr1 = rc.segrow[(size_t)g * (RES_MAXROWS + 1) + lane + 1];
+  }
+  if (t == 0) sc[3] = 0.0;
+  __syncthreads();
+  double gam_old = 0.0, alp_old = 0.0;
+  int iters = 0, nx = 0;
+  bool conv = false, bad = false, failed = false;
+  while (true) {
+    const unsigned tag = ep0 + 1u + (unsigned)nx;
+    const int par = (int)(tag & 1u);
+    ++nx;
+    RTL(0);
+    // ---- exchange (1): u ----
+    if (wv == 0) {
+      if (own) {
+        u32x2 d; d.x = (unsigned)__double2loint(u_); d.y = (unsigned)__double2hiint(u_);
+        __builtin_amdgcn_raw_buffer_store_b64(d, res_rsrc(rc.ubuf + (size_t)par * npad, (size_t)npad * 8), j * 8, 0, AUX_SC1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(rc.flags + (size_t)g * 16, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long t0 = wall_clock64();
+      while (true) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int o = lane + 64 * q;
+          if (o < nwg) {
+            const unsigned f = __hip_atomic_load(rc.flags + (size_t)o * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok &= (int)(f - tag) >= 0;
+          }
+        }
+        if (__all(ok)) break;
+        if (wall_clock64() - t0 > RES_WAIT_TICKS || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) sc[3] = 1.0; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
+    RTL(1);
+    if (sc[3] != 0.0) { failed = true; break; }
+    {
+      const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.ubuf + (size_t)par * npad, (size_t)npad * 8);
+      const int half = npad >> 1;
+      u32x4 v[RES_MAXLD];              // every load of the sweep in flight at once
+#pragma unroll
+      for (int q = 0; q < RES_MAXLD; ++q) { const int i2 = q * RES_TB + t; if (i2 < half) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, i2 * 16, 0, AUX_SC1); }
+#pragma unroll
+      for (int q = 0; q < RES_MAXLD; ++q) {
+        const int i2 = q * RES_TB + t;
+        if (i2 < half) { uv[2 * i2] = __hiloint2double((int)v[q].y, (int)v[q].x); uv[2 * i2 + 1] = __hiloint2double((int)v[q].w, (int)v[q].z); }
+      }
+    }
+    __syncthreads();
+    RTL(2);
+    // ---- rows of K times u: E products per thread, row segments to LDS ----
+    {
+      double s = 0.0; int slot = slot0;
+#pragma unroll
+      for (int k = 0; k < E; ++k) {
+        s += kv[k] * uv[kc[k]];
+        if ((brk >> k) & 1ull) { seg[slot++] = s; s = 0.0; }
+      }
+    }
+    __syncthreads();
+    RTL(3);
+    // ---- exchange (2): the dot partials ----
+    if (wv == 0) {
+      double pg = 0.0, pd = 0.0, prr = 0.0;
+      if (own) {
+        double a = 0.0;
+        for (int q0 = sr0; q0 < sr1; q0 += 16) {       // 16 independent LDS reads in flight, summed in slot order
+          double sv[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) sv[q] = q0 + q < sr1 ? seg[q0 + q] : 0.0;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) a += sv[q];
+        }
+        w_ = a;
+        pg = r_ * u_; pd = w_ * u_; prr = r_ * r_;
+      }
+      pg = wave_sum(pg); pd = wave_sum(pd); prr = wave_sum(prr);
+      const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.sbuf + (size_t)par * nwg * 8, (size_t)nwg * 64);
+      if (lane < 3) {
+        const double v = lane == 0 ? pg : (lane == 1 ? pd : prr);
+        u32x4 d; d.x = (unsigned)__double2loint(v); d.y = (unsigned)__double2hiint(v); d.z = tag; d.w = tag;
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (g * 4 + lane) * 16, 0, AUX_SC1);
+      }
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      unsigned pend = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (lane + 64 * q < nwg) pend |= 7u << (3 * q);
+      u32x4 gr[12];
+      const long long t0 = wall_clock64();
+      while (true) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q)
+          if (pend & (1u << q)) gr[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((lane + 64 * (q / 3)) * 4 + (q % 3)) * 16, 0, AUX_SC1);
+#pragma unroll
+        for (int q = 0; q < 12; ++q)
+          if ((pend & (1u << q)) && gr[q].z == tag && gr[q].w == tag) pend &= ~(1u << q);
+        if (__all(pend == 0)) break;
+        asm volatile("" ::: "memory");
+        if (wall_clock64() - t0 > RES_WAIT_TICKS || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) sc[3] = 1.0; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (lane + 64 * q < nwg) {
+          a0 += __hiloint2double((int)gr[3 * q].y, (int)gr[3 * q].x);
+          a1 += __hiloint2double((int)gr[3 * q + 1].y, (int)gr[3 * q + 1].x);
+          a2 += __hiloint2double((int)gr[3 * q + 2].y, (int)gr[3 * q + 2].x);
+        }
+      a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+      if (lane == 0) { sc[0] = a0; sc[1] = a1; sc[2] = a2; }
+    }
+    __syncthreads();
+    RTL(4);
+    if (sc[3] != 0.0) { failed = true; break; }
+    const double gam = sc[0], del = sc[1], rr = sc[2];
+    const CgStep cs = cg_step(rr, gam, del, gam_old, alp_old, tol2, iters, 0, prm, false);
+    if (cs.stop) { conv = cs.conv; bad = cs.bad && !cs.conv; break; }
+    ++iters; gam_old = gam; alp_old = cs.alpha;
+    if (own) {
+      p_ = cs.first ? u_ : (u_ + cs.beta * p_);
+      s_ = cs.first ? w_ : (w_ + cs.beta * s_);
+      x_ += cs.alpha * p_;
+      r_ -= cs.alpha * s_;
+      u_ = mi * r_;
+    }
+  }
+  if (failed) {
+    if (t == 0) __hip_atomic_store(&st->res_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (own && iters > 0) c.va[j] = x_;
+#ifdef OSQP_AMD_TIMELINE
+  if (g == 0 && t == 0) {
+    const int cnt = (nx < 64 ? nx : 64) * 5;
+    const unsigned long long k0 = atomicAdd(c.tl, (unsigned long long)cnt + 1);
+    if (k0 + cnt + 1 < TL_CAP - 2) {
+      for (int q = 0; q < cnt; ++q) c.tl[1 + k0 + q] = ((unsigned long long)(10 + q % 5) << 56) | ((unsigned long long)tls[q] & 0x00FFFFFFFFFFFFFFull);
+      c.tl[1 + k0 + cnt] = (15ull << 56) | (wall_clock64() & 0x00FFFFFFFFFFFFFFull);
+    }
+  }
+#endif
+  if (g == 0 && t == 0) {
+    st->iters[0] = iters; st->iters[1] = 0;
+    st->done = conv ? 1 : 2;
+    if (bad) st->neg_curv = 1;
+    st->tol2 = tol2;
+    st->res_epoch = ep0 + (unsigned)nx;
   }
 }
 
@@ -1303,6 +1577,11 @@ struct hipeng {
   hipeng_stats stats{};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   long long admm_done_seen = 0;
+  bool res_on = false;       // resident PCG structures built (problem fits the register files)
+  bool res_use = false;      // ... and in use (cleared for good when a launch found the grid not co-resident)
+  ResCtx rc{};
+  size_t res_lds = 0;
+  long long res_nnz = 0;
 };
 
 template <typename T>
@@ -1523,6 +1802,156 @@ static int repack_dense(hipeng *e) {
   return 0;
 }
 
+
+// ---- resident PCG: symbolic K, row partition, register layout --------------------------------------
+static std::mutex g_res_mu[16];
+static const int RES_E_LIST[] = {8, 16, 20, 24, 32, 48, 64};
+
+template <int E> static int res_set_lds(size_t lds) {
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pcg_resident<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return 0;
+}
+static void launch_resident(hipeng *e) {
+  const dim3 g(e->rc.nwg), b(RES_TB);
+  switch (e->rc.E) {
+    case 8:  hipLaunchKernelGGL(k_pcg_resident<8>,  g, b, e->res_lds, e->stream, e->c, e->rc); break;
+    case 16: hipLaunchKernelGGL(k_pcg_resident<16>, g, b, e->res_lds, e->stream, e->c, e->rc); break;
+    case 20: hipLaunchKernelGGL(k_pcg_resident<20>, g, b, e->res_lds, e->stream, e->c, e->rc); break;
+    case 24: hipLaunchKernelGGL(k_pcg_resident<24>, g, b, e->res_lds, e->stream, e->c, e->rc); break;
+    case 32: hipLaunchKernelGGL(k_pcg_resident<32>, g, b, e->res_lds, e->stream, e->c, e->rc); break;
+    case 48: hipLaunchKernelGGL(k_pcg_resident<48>, g, b, e->res_lds, e->stream, e->c, e->rc); break;
+    default: hipLaunchKernelGGL(k_pcg_resident<64>, g, b, e->res_lds, e->stream, e->c, e->rc); break;
+  }
+}
+
+// Returns 0 (with e->res_on set when the problem qualifies) or a HIPENG error.  Not qualifying is not an error.
+static int build_resident(hipeng *e) {
+  e->res_on = e->res_use = false;
+  const int n = e->n;
+  int want = 1, min_n = 256;
+  if (const char *x = getenv("OSQP_AMD_RESIDENT")) want = atoi(x);
+  if (const char *x = getenv("OSQP_AMD_RESIDENT_MIN_N")) min_n = atoi(x);
+  if (!want || n < min_n || n > RES_MAXN || !e->dP_blks.empty() || !e->hrows.empty() || e->A.blk.size() > (size_t)e->A.nwave) return 0;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, e->device));
+  const int nwg = std::min(256, prop.multiProcessorCount);
+  if ((long long)nwg * RES_MAXROWS < n || prop.sharedMemPerBlock < 64 * 1024) return 0;
+  const HostMat &M = e->M, &A = e->A;
+  for (int i = 0; i < n; i++)
+    for (int k = M.split[i] + 1; k < M.rowptr[i + 1]; k++) if (M.col[k] <= M.col[k - 1]) return 0;   // the merge in k_form_K wants ascending rows
+  // pattern of K, row by row (sorted), with the slot of P(i,j) in M
+  const size_t cap_total = (size_t)nwg * RES_TB * 64;
+  std::vector<int> Kptr(n + 1, 0), Kcol, Kps, mark(n, -1), pslot(n, -1);
+  Kcol.reserve(1 << 20); Kps.reserve(1 << 20);
+  for (int i = 0; i < n; i++) {
+    const size_t start = Kcol.size();
+    auto add = [&](int j) { if (mark[j] != i) { mark[j] = i; pslot[j] = -1; Kcol.push_back(j); } };
+    add(i);
+    for (int k = M.rowptr[i]; k < M.split[i]; k++) {
+      const int j = M.col[k];
+      add(j);
+      if (pslot[j] != -1) return 0;                 // a repeated entry of P: keep the general path
+      pslot[j] = k;
+    }
+    for (int k = M.split[i]; k < M.rowptr[i + 1]; k++) {
+      const int row = M.col[k] - n;
+      for (int q = A.rowptr[row]; q < A.rowptr[row + 1]; q++) add(A.col[q]);
+    }
+    if (Kcol.size() > cap_total) return 0;
+    std::sort(Kcol.begin() + start, Kcol.end());
+    Kps.resize(Kcol.size());
+    for (size_t q = start; q < Kcol.size(); q++) Kps[q] = pslot[Kcol[q]];
+    Kptr[i + 1] = (int)Kcol.size();
+  }
+  const long long nnzK = Kptr[n];
+  // contiguous row blocks, at most RES_MAXROWS rows and C entries each: smallest C that needs <= nwg blocks
+  auto packs = [&](long long C) -> int {
+    int g = 0, rows = 0; long long cnt = 0;
+    for (int i = 0; i < n; i++) {
+      const int len = Kptr[i + 1] - Kptr[i];
+      if (len > C) return 1 << 30;
+      if (rows > 0 && (cnt + len > C || rows == RES_MAXROWS)) { g++; cnt = 0; rows = 0; }
+      cnt += len; rows++;
+    }
+    return g + 1;
+  };
+  long long lo = 1, hi = std::max<long long>(nnzK, 1);
+  for (int i = 0; i < n; i++) lo = std::max<long long>(lo, Kptr[i + 1] - Kptr[i]);
+  if (packs(hi) > nwg) return 0;
+  while (lo < hi) { const long long mid = (lo + hi) / 2; if (packs(mid) <= nwg) hi = mid; else lo = mid + 1; }
+  const long long C = lo;
+  int E = 0;
+  for (int cand : RES_E_LIST) if ((long long)cand * RES_TB >= C) { E = cand; break; }
+  if (!E) return 0;
+  std::vector<ResWG> wg(nwg, ResWG{n, 0, 0, 0});
+  {
+    int g = 0, rows = 0; long long cnt = 0; wg[0].r0 = 0;
+    for (int i = 0; i < n; i++) {
+      const int len = Kptr[i + 1] - Kptr[i];
+      if (rows > 0 && (cnt + len > C || rows == RES_MAXROWS)) { wg[g].nr = rows; wg[g].cnt = (int)cnt; g++; wg[g].r0 = i; cnt = 0; rows = 0; }
+      cnt += len; rows++;
+    }
+    wg[g].nr = rows; wg[g].cnt = (int)cnt;
+  }
+  const size_t slots = (size_t)nwg * E * RES_TB;
+  std::vector<unsigned short> col(slots, 0), slot0((size_t)nwg * RES_TB, 0), segrow((size_t)nwg * (RES_MAXROWS + 1), 0);
+  std::vector<unsigned char> rowl(slots, 0);
+  std::vector<int> psrc(slots, -1);
+  std::vector<unsigned long long> brk((size_t)nwg * RES_TB, 0ull);
+  for (int g = 0; g < nwg; g++) {
+    const ResWG &w = wg[g];
+    if (w.nr == 0) continue;
+    const int base = Kptr[w.r0];
+    std::vector<int> rowof(w.cnt);
+    for (int r = 0; r < w.nr; r++)
+      for (int q = Kptr[w.r0 + r] - base; q < Kptr[w.r0 + r + 1] - base; q++) rowof[q] = r;
+    int nseg = 0, next_row = 0;
+    for (int t = 0; t < RES_TB; t++) {
+      slot0[(size_t)g * RES_TB + t] = (unsigned short)nseg;
+      unsigned long long b = 0;
+      for (int k = 0; k < E; k++) {
+        const int le = t * E + k;
+        if (le >= w.cnt) break;
+        const size_t sl = ((size_t)g * E + k) * RES_TB + t;
+        col[sl] = (unsigned short)Kcol[base + le]; rowl[sl] = (unsigned char)rowof[le]; psrc[sl] = Kps[base + le];
+        while (next_row <= rowof[le]) segrow[(size_t)g * (RES_MAXROWS + 1) + next_row++] = (unsigned short)nseg;   // first segment of the row
+        const bool last = k == E - 1 || le + 1 >= w.cnt || rowof[le + 1] != rowof[le];
+        if (last) { b |= 1ull << k; nseg++; }
+      }
+      brk[(size_t)g * RES_TB + t] = b;
+    }
+    for (int r = next_row; r <= RES_MAXROWS; r++) segrow[(size_t)g * (RES_MAXROWS + 1) + r] = (unsigned short)nseg;
+    if (nseg > RES_TB + RES_MAXROWS) return 0;   // cannot happen (one segment per thread plus one per row change)
+  }
+  ResCtx rc{};
+  rc.nwg = nwg; rc.E = E; rc.npad = (n + 1) & ~1;
+  ResWG *d_wg = nullptr; unsigned short *d_col = nullptr, *d_slot0 = nullptr, *d_segrow = nullptr; unsigned char *d_rowl = nullptr;
+  int *d_psrc = nullptr; unsigned long long *d_brk = nullptr;
+  if (dev_alloc(e, &d_wg, wg.size()) || dev_alloc(e, &rc.val, slots) || dev_alloc(e, &d_col, slots) || dev_alloc(e, &d_rowl, slots) ||
+      dev_alloc(e, &d_psrc, slots) || dev_alloc(e, &d_brk, brk.size()) || dev_alloc(e, &d_slot0, slot0.size()) ||
+      dev_alloc(e, &d_segrow, segrow.size()) || dev_alloc(e, &rc.ubuf, (size_t)2 * rc.npad) ||
+      dev_alloc(e, &rc.flags, (size_t)nwg * 16) || dev_alloc(e, &rc.sbuf, (size_t)2 * nwg * 8)) return HIPENG_ERR_HIP;
+#define UP(dst, src) HIPCHK(hipMemcpyAsync(dst, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, e->stream))
+  UP(d_wg, wg); UP(d_col, col); UP(d_rowl, rowl); UP(d_psrc, psrc); UP(d_brk, brk); UP(d_slot0, slot0); UP(d_segrow, segrow);
+#undef UP
+  HIPCHK(hipStreamSynchronize(e->stream));       // the sources are locals
+  rc.wg = d_wg; rc.col = d_col; rc.rowl = d_rowl; rc.psrc = d_psrc; rc.brk = d_brk; rc.slot0 = d_slot0; rc.segrow = d_segrow;
+  e->rc = rc;
+  e->res_lds = ((size_t)rc.npad + RES_TB + RES_MAXROWS + 16 + 5 * 64) * sizeof(double);   // + phase stamps of the TIMELINE build
+  int rcode = 0;
+  switch (E) {
+    case 8: rcode = res_set_lds<8>(e->res_lds); break;   case 16: rcode = res_set_lds<16>(e->res_lds); break;
+    case 20: rcode = res_set_lds<20>(e->res_lds); break; case 24: rcode = res_set_lds<24>(e->res_lds); break;
+    case 32: rcode = res_set_lds<32>(e->res_lds); break; case 48: rcode = res_set_lds<48>(e->res_lds); break;
+    default: rcode = res_set_lds<64>(e->res_lds); break;
+  }
+  if (rcode) return rcode;
+  e->res_nnz = nnzK;
+  e->res_on = e->res_use = true;
+  if (e->trace) fprintf(stderr, "[osqp_amd] resident PCG: nnz(K)=%lld, %d workgroups x %d threads x %d entries, %zu B LDS\n", nnzK, nwg, RES_TB, E, e->res_lds);
+  return 0;
+}
+
 static int elem_grid(int cnt) {
   int g = (cnt + TB - 1) / TB;
   return std::max(1, std::min(g, MAX_PARTS));
@@ -1531,6 +1960,7 @@ static int elem_grid(int cnt) {
 // Everything derived from (P, A, rho, sigma): the Jacobi preconditioner.
 static void refresh_operator(hipeng *e) {
   hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
+  if (e->res_on) hipLaunchKernelGGL(k_form_K, dim3(1024), dim3(TB), 0, e->stream, e->c, e->rc);
 }
 
 // The PCG start vector history is void (cold/warm start from the host, new rho, new matrices):
@@ -1666,6 +2096,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
       upload_vec(e, c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
   e->stats.kernels_per_pcg_iter = 2;
   *out = e;
+  if (int rc = build_resident(e)) return rc;
   if (rho_vec) { int rc = hipeng_upload_rho(e, rho_vec); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
@@ -1946,7 +2377,8 @@ static int get_graph(hipeng *e, int K, int R, int spec_lo, hipGraphExec_t *out) 
   HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
   for (int seg = 0; seg < R; seg++) {
     launch_init(e);
-    launch_cg_A(e, -1, 8); launch_cg_B(e, -1, 0);   // operator apply on u0 (+ first convergence test), then w0 and the first dots
+    if (K == 0) launch_resident(e);                   // the whole linear solve in one launch (K in registers)
+    else { launch_cg_A(e, -1, 8); launch_cg_B(e, -1, 0); }   // operator apply on u0 (+ first convergence test), then w0 and the first dots
     for (int it = 0; it < K; it++) launch_pcg_iter(e, it, 0, spec_lo);
     if (e->c.A.nblk > e->c.A.nwave) hipLaunchKernelGGL(k_huge_dot, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, (const double *)nullptr, 0);
     hipLaunchKernelGGL(k_admm_finalize, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c);
@@ -2010,18 +2442,33 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   while (remaining > 0) {
     // after a reset (cold start, new rho, new matrices) the PCG iteration count jumps: two
     // iterations to see where it lands, then whole windows
-    const long long burst = std::min<long long>(remaining, e->calibrated ? 128 : 2);
+    const bool resident = e->res_use;
+    // A resident launch needs every CU for itself (one workgroup per CU, all co-resident): resident windows of
+    // different engines of this process on one device take turns.  (Across processes there is no such lock: a
+    // launch that finds CUs taken times out and the engine falls back, see k_pcg_resident.)
+    std::unique_lock<std::mutex> lease;
+    if (resident) lease = std::unique_lock<std::mutex>(g_res_mu[e->device & 15]);
+    const long long burst = std::min<long long>(remaining, (e->calibrated || resident) ? 128 : 2);
     TR2(e, "launch burst=%lld K=%d", burst, e->K);
     // `burst` ADMM iterations = burst / segs graphs of `segs` segments + single-segment graphs for the rest
     // (graphs with many nodes only when the unroll is short: keeps instantiation cheap for long PCG runs)
-    const int R = e->K <= 48 ? segs : 1;
+    const int R = (resident || e->K <= 48) ? segs : 1;
+    const int gK = resident ? 0 : e->K, gS = resident ? 0 : e->spec_lo;
     hipGraphExec_t gR = nullptr, g1 = nullptr;
-    if (burst >= R && R > 1 && get_graph(e, e->K, R, e->spec_lo, &gR)) return HIPENG_ERR_HIP;
-    if ((!gR || burst % R) && get_graph(e, e->K, 1, e->spec_lo, &g1)) return HIPENG_ERR_HIP;
+    if (burst >= R && R > 1 && get_graph(e, gK, R, gS, &gR)) return HIPENG_ERR_HIP;
+    if ((!gR || burst % R) && get_graph(e, gK, 1, gS, &g1)) return HIPENG_ERR_HIP;
     long long left = burst;
     for (; gR && left >= R; left -= R) { HIPCHK(hipGraphLaunch(gR, e->stream)); e->stats.graph_launches += 1; }
     for (; left > 0; left--) { HIPCHK(hipGraphLaunch(g1, e->stream)); e->stats.graph_launches += 1; }
     if (read_state(e, &s)) return HIPENG_ERR_HIP;
+    if (lease.owns_lock()) lease.unlock();
+    if (s.res_fail) {
+      // the resident launch found its grid not co-resident (the GPU is shared): launch-per-step kernels from here on
+      fprintf(stderr, "osqp_amd: resident PCG launch timed out waiting for its workgroups (GPU shared with another stream or process?); "
+                      "continuing with the launch-per-step path\n");
+      e->res_use = false;
+      HIPCHK(hipMemsetAsync(&e->c.st->res_fail, 0, sizeof(int), e->stream));
+    }
     const long long done_now = s.admm_done - start;
     const bool stalls = count - done_now > remaining - burst;       // some launches were continuations
     remaining = count - done_now;

@@ -43,3 +43,11 @@ if hasattr(L, "hipeng_timeline"):      # make TIMELINE=1 build: where the time o
             names[i], p.size, act.size, act[act < 30].mean() if (act < 30).any() else 0, act[act < 30].sum(), noop.size, noop.mean() if noop.size else 0, noop.sum(),
             (p >= 30).sum(), p[p >= 30].sum()))
     print("  per ADMM iteration: %.1f us total" % ((ts[-1] - ts[0]) / r.info.iter))
+    if (ids == 5).any():       # resident PCG launches: phases of workgroup 0
+        names = {5: "resident start", 10: "iteration top", 11: "flags seen", 12: "vector in LDS", 13: "products done", 14: "scalars in", 15: "kernel end"}
+        nxt = {}
+        for a, b, d in zip(ids[:-1], ids[1:], per):
+            nxt.setdefault((a, b), []).append(d)
+        for (a, b), v in sorted(nxt.items()):
+            v = np.array(v)
+            print("  %-16s -> %-16s %7d x mean %6.2f us (min %5.2f, max %6.2f)" % (names.get(a, a), names.get(b, b), v.size, v.mean(), v.min(), v.max()))
