@@ -110,6 +110,8 @@ struct State {
   long long admm_target;   // k_pcg_init starts no new ADMM iteration once admm_done has reached this
   unsigned res_epoch;      // resident PCG: tag of the last exchange of the previous launch
   int    res_fail;         // resident PCG: a wait timed out (workgroups not co-resident); the host falls back to the launch-per-step path
+  int    res_pipe_off;     // resident PCG: the pipelined recurrences failed a true-residual check for this K (k_form_K clears it)
+  int    res_ver_cnt;      // resident PCG: solves since K last changed (which of them are checked: k_pcg_resident)
 };
 
 struct Params {          // mutable scalars (host writes, kernels read)
@@ -946,6 +948,7 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
 // launch gives up, sets State::res_fail, and the host continues with the launch-per-step kernels.
 // ---------------------------------------------------------------------------
 #define RES_TB 512
+#define RES_PT (RES_TB - 64)   // threads that hold entries of K (wavefronts 1..7); wavefront 0 owns the rows and talks
 #define RES_MAXROWS 64
 #define RES_MAXN (RES_MAXROWS * 256)
 #define RES_MAXLD (RES_MAXN / 2 / RES_TB)   // 16-byte loads per thread that sweep the exchanged vector
@@ -956,15 +959,16 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 struct ResWG { int r0, nr, cnt, pad; };   // first row, rows (<= RES_MAXROWS), entries of K
 struct ResCtx {
   int nwg, E, npad;                  // workgroups, entries per thread, n rounded up to even
+  int pipe;                          // 1: pipelined recurrences where they pass their checks (OSQP_AMD_RESIDENT_PIPE=0: never)
   const ResWG *wg;
-  double *val;                       // [nwg][E][RES_TB]: entry t*E + k of the workgroup's row-major list at (k, t)
+  double *val;                       // [nwg][E][RES_PT]: entry t*E + k of the workgroup's row-major list at (k, t)
   const unsigned short *col;         // same layout
   const unsigned char *rowl;         // same layout: local row of the entry
   const int *psrc;                   // same layout: slot in M of P(i,j), -1 if none
-  const unsigned long long *brk;     // [nwg][RES_TB]: bit k set = entry k ends a row segment of this thread
-  const unsigned short *slot0;       // [nwg][RES_TB]: first segment slot of the thread
+  const unsigned long long *brk;     // [nwg][RES_PT]: bit k set = entry k ends a row segment of this thread
+  const unsigned short *slot0;       // [nwg][RES_PT]: first segment slot of the thread
   const unsigned short *segrow;      // [nwg][RES_MAXROWS + 1]: first segment slot of each local row
-  double *ubuf;                      // 2 x npad doubles (parity of the tag)
+  double *ubuf;                      // 2 x (npad + 4 * 256) doubles (parity of the tag): the vector, then 4 doubles per workgroup
   unsigned *flags;                   // nwg x 16 words (one 64-byte line each)
   double *sbuf;                      // 2 x nwg x 4 granules {double, tag}
 };
@@ -978,9 +982,10 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const void *p,
 // order for (i,j) and (j,i), so K is symmetric to the bit.
 __global__ void __launch_bounds__(TB) k_form_K(Ctx c, ResCtx rc) {
   const double sigma = c.prm->sigma;
-  const size_t total = (size_t)rc.nwg * rc.E * RES_TB;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { c.st->res_pipe_off = 0; c.st->res_ver_cnt = 0; }
+  const size_t total = (size_t)rc.nwg * rc.E * RES_PT;
   for (size_t sl = (size_t)blockIdx.x * TB + threadIdx.x; sl < total; sl += (size_t)gridDim.x * TB) {
-    const int t = (int)(sl % RES_TB), k = (int)((sl / RES_TB) % rc.E), g = (int)(sl / ((size_t)RES_TB * rc.E));
+    const int t = (int)(sl % RES_PT), k = (int)((sl / RES_PT) % rc.E), g = (int)(sl / ((size_t)RES_PT * rc.E));
     const ResWG w = rc.wg[g];
     double v = 0.0;
     if (t * rc.E + k < w.cnt) {
@@ -1005,28 +1010,44 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   TL_MARK(c, 5);
   if (st->stalled || !st->run || st->res_fail) return;
   double *uv = rlds;                              // npad doubles: the exchanged vector
-  double *seg = uv + rc.npad;                     // RES_TB + RES_MAXROWS row-segment sums
+  double *tail = uv + rc.npad;                    // 4 doubles per workgroup riding with the vector: dot partials
+  double *seg = tail + 4 * 256;                   // RES_TB + RES_MAXROWS row-segment sums
   double *sc = seg + RES_TB + RES_MAXROWS;        // 4 doubles: gamma, delta, rr, fail word
 #ifdef OSQP_AMD_TIMELINE
-  long long *tls = reinterpret_cast<long long *>(sc + 8);   // phase stamps of the first 64 iterations (workgroup 0)
-#define RTL(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && nx <= 64) tls[(nx - 1) * 5 + (k)] = wall_clock64(); } while (0)
+  long long *tls = reinterpret_cast<long long *>(sc + 8);   // phase stamps of the first 64 exchanges (workgroup 0)
+#define RTL(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && nx >= 1 && nx <= 64) tls[(nx - 1) * 5 + (k)] = wall_clock64(); } while (0)
+  long long *wtl = tls + 5 * 64;                             // [phase][wavefront] stamps of exchange 8 (workgroup 0)
+#define WTL(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && nx == 8) wtl[(k) * 8 + (threadIdx.x >> 6)] = wall_clock64(); } while (0)
 #else
 #define RTL(k) do { } while (0)
+#define WTL(k) do { } while (0)
 #endif
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int nwg = rc.nwg, npad = rc.npad;
   const ResWG w = rc.wg[g];
   const Params prm = *c.prm;
   const unsigned ep0 = st->res_epoch;
+  const int ver_cnt = st->res_ver_cnt;  // (checks were sampled by this count at first; that let drifting solves through: 625 instead of 200 ADMM iterations on a cond 1e6 system at eps 1e-9.  Every pipelined solve is checked now.)
+  // pipelined recurrences only where a drift would be caught: not in the convexity probe, not after a failed check
+  bool pipe = rc.pipe && !st->res_pipe_off && !prm.no_restart;
   // ---- own slice of K into registers (issued first: in flight under everything below) ----
+  // (wavefronts 1..7; wavefront 0 holds no entries: its loads are the small ones the start-up and the exchanges wait for)
+  const bool prod = wv != 0;
+  const int tt = t - 64;
   double kv[E]; unsigned short kc[E];
 #pragma unroll
-  for (int k = 0; k < E; ++k) {
-    const size_t idx = ((size_t)g * E + k) * RES_TB + t;
-    kv[k] = rc.val[idx]; kc[k] = rc.col[idx];
+  for (int k = 0; k < E; ++k) { kv[k] = 0.0; kc[k] = 0; }
+  unsigned long long brk = 0ull;
+  int slot0 = 0;
+  if (prod) {
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const size_t idx = ((size_t)g * E + k) * RES_PT + tt;
+      kv[k] = rc.val[idx]; kc[k] = rc.col[idx];
+    }
+    brk = rc.brk[(size_t)g * RES_PT + tt];
+    slot0 = rc.slot0[(size_t)g * RES_PT + tt];
   }
-  const unsigned long long brk = rc.brk[(size_t)g * RES_TB + t];
-  const int slot0 = rc.slot0[(size_t)g * RES_TB + t];
   int sr0 = 0, sr1 = 0;
   // ---- start-up scalars: ||r0||^2, ||b||^2 from k_pcg_init's partials (every wavefront, same order) ----
   double rr0 = 0.0, bb = 0.0;
@@ -1040,26 +1061,35 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   // rows of this workgroup live in the lanes of wavefront 0
   const bool own = wv == 0 && lane < w.nr;
   const int j = w.r0 + lane;
-  double r_ = 0, u_ = 0, w_ = 0, p_ = 0, s_ = 0, x_ = 0, mi = 0;
+  double r_ = 0, u_ = 0, w_ = 0, p_ = 0, s_ = 0, x_ = 0, mi = 0, x0_ = 0, r0_ = 0;
+  double z_ = 0, q_ = 0;               // pipelined recurrences: z = K q, q = Minv s
   if (own) {
     r_ = c.init_r[(size_t)j * c.init_stride]; u_ = c.init_z[j]; x_ = c.vx[j]; mi = c.minv[j];
+    x0_ = x_; r0_ = r_;
     sr0 = rc.segrow[(size_t)g * (RES_MAXROWS + 1) + lane]; sr1 = rc.segrow[(size_t)g * (RES_MAXROWS + 1) + lane + 1];
   }
   if (t == 0) sc[3] = 0.0;
   __syncthreads();
-  double gam_old = 0.0, alp_old = 0.0;
-  int iters = 0, nx = 0;
-  bool conv = false, bad = false, failed = false;
-  while (true) {
-    const unsigned tag = ep0 + 1u + (unsigned)nx;
-    const int par = (int)(tag & 1u);
-    ++nx;
+  int nx = 0;                          // vector exchanges so far; exchange k carries the tag ep0 + k
+  unsigned tag = ep0;
+  int par = 0;
+
+  // Exchange (1): every workgroup's rows of one vector (+ 3 doubles riding along) to every workgroup's LDS.
+  // Write-through stores, drain, flag; wavefront 0 polls the flags; sc1 sweep.  False when a wait timed out.
+  auto vec_exchange = [&](double val, double e0, double e1, double e2) __attribute__((always_inline)) -> bool {
+    ++nx; tag = ep0 + (unsigned)nx; par = (int)(tag & 1u);
     RTL(0);
-    // ---- exchange (1): u ----
+    const size_t stride = (size_t)npad + 4 * 256;
+    const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.ubuf + (size_t)par * stride, stride * 8);
     if (wv == 0) {
       if (own) {
-        u32x2 d; d.x = (unsigned)__double2loint(u_); d.y = (unsigned)__double2hiint(u_);
-        __builtin_amdgcn_raw_buffer_store_b64(d, res_rsrc(rc.ubuf + (size_t)par * npad, (size_t)npad * 8), j * 8, 0, AUX_SC1);
+        u32x2 d; d.x = (unsigned)__double2loint(val); d.y = (unsigned)__double2hiint(val);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rs, j * 8, 0, AUX_SC1);
+      }
+      if (lane < 3) {
+        const double v = lane == 0 ? e0 : (lane == 1 ? e1 : e2);
+        u32x2 d; d.x = (unsigned)__double2loint(v); d.y = (unsigned)__double2hiint(v);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rs, (npad + 4 * g + lane) * 8, 0, AUX_SC1);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(rc.flags + (size_t)g * 16, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1082,47 +1112,65 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __syncthreads();
     RTL(1);
-    if (sc[3] != 0.0) { failed = true; break; }
+    if (sc[3] != 0.0) return false;
     {
-      const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.ubuf + (size_t)par * npad, (size_t)npad * 8);
       const int half = npad >> 1;
       u32x4 v[RES_MAXLD];              // every load of the sweep in flight at once
+      u32x4 vt;
 #pragma unroll
       for (int q = 0; q < RES_MAXLD; ++q) { const int i2 = q * RES_TB + t; if (i2 < half) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, i2 * 16, 0, AUX_SC1); }
+      if (t < 2 * nwg) vt = __builtin_amdgcn_raw_buffer_load_b128(rs, (half + t) * 16, 0, AUX_SC1);
 #pragma unroll
       for (int q = 0; q < RES_MAXLD; ++q) {
         const int i2 = q * RES_TB + t;
         if (i2 < half) { uv[2 * i2] = __hiloint2double((int)v[q].y, (int)v[q].x); uv[2 * i2 + 1] = __hiloint2double((int)v[q].w, (int)v[q].z); }
       }
+      if (t < 2 * nwg) { tail[2 * t] = __hiloint2double((int)vt.y, (int)vt.x); tail[2 * t + 1] = __hiloint2double((int)vt.w, (int)vt.z); }
     }
     __syncthreads();
     RTL(2);
-    // ---- rows of K times u: E products per thread, row segments to LDS ----
-    {
+    return true;
+  };
+  // rows of K times the vector in LDS: E products per thread, row segments through LDS; the own-row value
+  // in the lanes of wavefront 0 (ends with the barrier that makes the segments visible)
+  auto products_issue = [&]() __attribute__((always_inline)) {
+    if (prod) {
+      // gathers first (all in flight together; the segment writes below could alias them as far as the compiler knows),
+      // half of the entries at a time to stay inside the register budget
       double s = 0.0; int slot = slot0;
+      constexpr int H = (E + 1) / 2;
 #pragma unroll
-      for (int k = 0; k < E; ++k) {
-        s += kv[k] * uv[kc[k]];
-        if ((brk >> k) & 1ull) { seg[slot++] = s; s = 0.0; }
+      for (int h = 0; h < 2; ++h) {
+        double xv[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) if (h * H + k < E) xv[k] = uv[kc[h * H + k]];
+#pragma unroll
+        for (int k = 0; k < H; ++k)
+          if (h * H + k < E) {
+            s += kv[h * H + k] * xv[k];
+            if ((brk >> (h * H + k)) & 1ull) { seg[slot++] = s; s = 0.0; }
+          }
       }
     }
+  };
+  auto products_finish = [&]() __attribute__((always_inline)) -> double {
     __syncthreads();
     RTL(3);
-    // ---- exchange (2): the dot partials ----
-    if (wv == 0) {
-      double pg = 0.0, pd = 0.0, prr = 0.0;
-      if (own) {
-        double a = 0.0;
-        for (int q0 = sr0; q0 < sr1; q0 += 16) {       // 16 independent LDS reads in flight, summed in slot order
-          double sv[16];
+    double a = 0.0;
+    if (own)
+      for (int q0 = sr0; q0 < sr1; q0 += 16) {       // 16 independent LDS reads in flight, summed in slot order
+        double sv[16];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) sv[q] = q0 + q < sr1 ? seg[q0 + q] : 0.0;
+        for (int q = 0; q < 16; ++q) sv[q] = seg[min(q0 + q, sr1 - 1)];     // unconditional: no branch per read
 #pragma unroll
-          for (int q = 0; q < 16; ++q) a += sv[q];
-        }
-        w_ = a;
-        pg = r_ * u_; pd = w_ * u_; prr = r_ * r_;
+        for (int q = 0; q < 16; ++q) a += q0 + q < sr1 ? sv[q] : 0.0;
       }
+    return a;
+  };
+  auto products = [&]() __attribute__((always_inline)) -> double { products_issue(); return products_finish(); };
+  // Exchange (2): three dot partials per workgroup as {value, tag} granules (the data is the flag); totals in sc[0..2].
+  auto scal_exchange = [&](double pg, double pd, double prr) __attribute__((always_inline)) -> bool {
+    if (wv == 0) {
       pg = wave_sum(pg); pd = wave_sum(pd); prr = wave_sum(prr);
       const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.sbuf + (size_t)par * nwg * 8, (size_t)nwg * 64);
       if (lane < 3) {
@@ -1160,7 +1208,95 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
     }
     __syncthreads();
     RTL(4);
-    if (sc[3] != 0.0) { failed = true; break; }
+    return sc[3] == 0.0;
+  };
+
+  double gam_old = 0.0, alp_old = 0.0;
+  int iters = 0;
+  bool conv = false, bad = false, failed = false, finished = false;
+
+  // ---- phase P: pipelined recurrences (Ghysels-Vanroose): ONE exchange per iteration.  m = Minv w travels with the
+  // partials of (r,u), (w,u), (r,r); every workgroup forms the scalars itself; w, u follow recurrences instead of a
+  // fresh product.  Those recurrences drift on ill-conditioned systems, so: out after 64 iterations, out on any
+  // breakdown, and every solve that claims convergence is checked against the true residual r0 - K (x - x0).
+  // A failed check hands the solve to phase C and switches phase P off until K changes.
+  bool to_check = false;
+  int check_why = 0;                   // 0: the recurrence says converged, 1: breakdown / iteration cap, 2: long solve
+  if (pipe) {
+    if (!vec_exchange(u_, 0.0, 0.0, 0.0)) failed = true;
+    else {
+      w_ = products();
+      while (true) {
+        const double m_ = mi * w_;
+        double pg = 0.0, pd = 0.0, prr = 0.0;
+        if (wv == 0) { if (own) { pg = r_ * u_; pd = w_ * u_; prr = r_ * r_; } pg = wave_sum(pg); pd = wave_sum(pd); prr = wave_sum(prr); }
+        if (!vec_exchange(m_, pg, pd, prr)) { failed = true; break; }
+        // K m by wavefronts 1..7 while every wavefront forms the scalars (the same sums in the same order); the
+        // products of the iteration that finds the stop are wasted
+        WTL(0);
+        // K m by wavefronts 1..7 while wavefront 0 (which holds no entries of K) forms the scalars and takes the
+        // step's decisions; its verdict reaches the others through LDS at the barrier.  The products of the iteration
+        // that finds the stop are wasted.
+        products_issue();
+        WTL(1);
+        CgStep cs{};
+        if (wv == 0) {
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (lane + 64 * q < nwg) { a0 += tail[4 * (lane + 64 * q)]; a1 += tail[4 * (lane + 64 * q) + 1]; a2 += tail[4 * (lane + 64 * q) + 2]; }
+          const double gam = wave_sum(a0), del = wave_sum(a1), rr = wave_sum(a2);
+          cs = cg_step(rr, gam, del, gam_old, alp_old, tol2, iters, 0, prm, false);
+          gam_old = gam; alp_old = cs.alpha;
+          if (lane == 0) sc[4] = cs.stop ? (cs.conv ? 1.0 : 2.0) : 0.0;
+        }
+        WTL(2);
+        const double n_ = products_finish();
+        const double verdict = sc[4];
+        WTL(3);
+        if (verdict != 0.0) { to_check = true; check_why = verdict == 1.0 ? 0 : 1; break; }
+        ++iters;
+        if (own) {
+          z_ = cs.first ? n_ : (n_ + cs.beta * z_);
+          q_ = cs.first ? m_ : (m_ + cs.beta * q_);
+          s_ = cs.first ? w_ : (w_ + cs.beta * s_);
+          p_ = cs.first ? u_ : (u_ + cs.beta * p_);
+          x_ += cs.alpha * p_;
+          r_ -= cs.alpha * s_;
+          u_ -= cs.alpha * q_;
+          w_ -= cs.alpha * z_;
+        }
+        WTL(4);
+        if (iters >= 64) { to_check = true; check_why = 2; break; }
+      }
+    }
+    if (to_check && !failed) {
+      // true residual of the current iterate
+      if (!vec_exchange(x_ - x0_, 0.0, 0.0, 0.0)) failed = true;
+      else {
+        const double kd = products();
+        const double rt = r0_ - kd;
+        if (!scal_exchange(0.0, 0.0, own ? rt * rt : 0.0)) failed = true;
+        else {
+          const double rrt = sc[2];
+          if (rrt <= 2.0 * tol2) { conv = true; finished = true; }
+          else {
+            // continue from the true residual with fresh directions in phase C; the recurrences are switched off for
+            // this K when they had claimed convergence or broken down (not when the solve was merely long)
+            if (own) { r_ = rt; u_ = mi * rt; }
+            gam_old = 0.0; alp_old = 0.0;
+            if (g == 0 && t == 0 && check_why != 2) st->res_pipe_off = 1;
+          }
+          __syncthreads();          // sc[] is rewritten by the next exchange
+        }
+      }
+    }
+  }
+
+  // ---- phase C: Chronopoulos-Gear with a fresh product every iteration (the recurrences of k_cg_A / k_cg_B) ----
+  while (!finished && !failed) {
+    if (!vec_exchange(u_, 0.0, 0.0, 0.0)) { failed = true; break; }
+    w_ = products();
+    if (!scal_exchange(own ? r_ * u_ : 0.0, own ? w_ * u_ : 0.0, own ? r_ * r_ : 0.0)) { failed = true; break; }
     const double gam = sc[0], del = sc[1], rr = sc[2];
     const CgStep cs = cg_step(rr, gam, del, gam_old, alp_old, tol2, iters, 0, prm, false);
     if (cs.stop) { conv = cs.conv; bad = cs.bad && !cs.conv; break; }
@@ -1186,6 +1322,11 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
       for (int q = 0; q < cnt; ++q) c.tl[1 + k0 + q] = ((unsigned long long)(10 + q % 5) << 56) | ((unsigned long long)tls[q] & 0x00FFFFFFFFFFFFFFull);
       c.tl[1 + k0 + cnt] = (15ull << 56) | (wall_clock64() & 0x00FFFFFFFFFFFFFFull);
     }
+    if (nx >= 8) {
+      const unsigned long long k1 = atomicAdd(c.tl, 40ull);
+      if (k1 + 40 < TL_CAP - 2)
+        for (int q = 0; q < 40; ++q) c.tl[1 + k1 + q] = ((unsigned long long)(20 + q) << 56) | ((unsigned long long)(wtl[q] - wtl[0]) & 0x00FFFFFFFFFFFFFFull);
+    }
   }
 #endif
   if (g == 0 && t == 0) {
@@ -1194,6 +1335,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
     if (bad) st->neg_curv = 1;
     st->tol2 = tol2;
     st->res_epoch = ep0 + (unsigned)nx;
+    st->res_ver_cnt = ver_cnt + 1;
   }
 }
 
@@ -1840,7 +1982,7 @@ static int build_resident(hipeng *e) {
   for (int i = 0; i < n; i++)
     for (int k = M.split[i] + 1; k < M.rowptr[i + 1]; k++) if (M.col[k] <= M.col[k - 1]) return 0;   // the merge in k_form_K wants ascending rows
   // pattern of K, row by row (sorted), with the slot of P(i,j) in M
-  const size_t cap_total = (size_t)nwg * RES_TB * 64;
+  const size_t cap_total = (size_t)nwg * RES_PT * 64;
   std::vector<int> Kptr(n + 1, 0), Kcol, Kps, mark(n, -1), pslot(n, -1);
   Kcol.reserve(1 << 20); Kps.reserve(1 << 20);
   for (int i = 0; i < n; i++) {
@@ -1881,7 +2023,7 @@ static int build_resident(hipeng *e) {
   while (lo < hi) { const long long mid = (lo + hi) / 2; if (packs(mid) <= nwg) hi = mid; else lo = mid + 1; }
   const long long C = lo;
   int E = 0;
-  for (int cand : RES_E_LIST) if ((long long)cand * RES_TB >= C) { E = cand; break; }
+  for (int cand : RES_E_LIST) if ((long long)cand * RES_PT >= C) { E = cand; break; }
   if (!E) return 0;
   std::vector<ResWG> wg(nwg, ResWG{n, 0, 0, 0});
   {
@@ -1893,11 +2035,12 @@ static int build_resident(hipeng *e) {
     }
     wg[g].nr = rows; wg[g].cnt = (int)cnt;
   }
-  const size_t slots = (size_t)nwg * E * RES_TB;
-  std::vector<unsigned short> col(slots, 0), slot0((size_t)nwg * RES_TB, 0), segrow((size_t)nwg * (RES_MAXROWS + 1), 0);
+  const size_t slots = (size_t)nwg * E * RES_PT;
+  const bool fake_col = getenv("OSQP_AMD_RES_FAKECOL") != nullptr;   // timing experiment: conflict-free LDS gathers (results are garbage)
+  std::vector<unsigned short> col(slots, 0), slot0((size_t)nwg * RES_PT, 0), segrow((size_t)nwg * (RES_MAXROWS + 1), 0);
   std::vector<unsigned char> rowl(slots, 0);
   std::vector<int> psrc(slots, -1);
-  std::vector<unsigned long long> brk((size_t)nwg * RES_TB, 0ull);
+  std::vector<unsigned long long> brk((size_t)nwg * RES_PT, 0ull);
   for (int g = 0; g < nwg; g++) {
     const ResWG &w = wg[g];
     if (w.nr == 0) continue;
@@ -1906,30 +2049,32 @@ static int build_resident(hipeng *e) {
     for (int r = 0; r < w.nr; r++)
       for (int q = Kptr[w.r0 + r] - base; q < Kptr[w.r0 + r + 1] - base; q++) rowof[q] = r;
     int nseg = 0, next_row = 0;
-    for (int t = 0; t < RES_TB; t++) {
-      slot0[(size_t)g * RES_TB + t] = (unsigned short)nseg;
+    for (int t = 0; t < RES_PT; t++) {
+      slot0[(size_t)g * RES_PT + t] = (unsigned short)nseg;
       unsigned long long b = 0;
       for (int k = 0; k < E; k++) {
         const int le = t * E + k;
         if (le >= w.cnt) break;
-        const size_t sl = ((size_t)g * E + k) * RES_TB + t;
-        col[sl] = (unsigned short)Kcol[base + le]; rowl[sl] = (unsigned char)rowof[le]; psrc[sl] = Kps[base + le];
+        const size_t sl = ((size_t)g * E + k) * RES_PT + t;
+        col[sl] = fake_col ? (unsigned short)((t + 64 * k) % n) : (unsigned short)Kcol[base + le]; rowl[sl] = (unsigned char)rowof[le]; psrc[sl] = Kps[base + le];
         while (next_row <= rowof[le]) segrow[(size_t)g * (RES_MAXROWS + 1) + next_row++] = (unsigned short)nseg;   // first segment of the row
         const bool last = k == E - 1 || le + 1 >= w.cnt || rowof[le + 1] != rowof[le];
         if (last) { b |= 1ull << k; nseg++; }
       }
-      brk[(size_t)g * RES_TB + t] = b;
+      brk[(size_t)g * RES_PT + t] = b;
     }
     for (int r = next_row; r <= RES_MAXROWS; r++) segrow[(size_t)g * (RES_MAXROWS + 1) + r] = (unsigned short)nseg;
     if (nseg > RES_TB + RES_MAXROWS) return 0;   // cannot happen (one segment per thread plus one per row change)
   }
   ResCtx rc{};
   rc.nwg = nwg; rc.E = E; rc.npad = (n + 1) & ~1;
+  rc.pipe = 1;
+  if (const char *x = getenv("OSQP_AMD_RESIDENT_PIPE")) rc.pipe = atoi(x) != 0;
   ResWG *d_wg = nullptr; unsigned short *d_col = nullptr, *d_slot0 = nullptr, *d_segrow = nullptr; unsigned char *d_rowl = nullptr;
   int *d_psrc = nullptr; unsigned long long *d_brk = nullptr;
   if (dev_alloc(e, &d_wg, wg.size()) || dev_alloc(e, &rc.val, slots) || dev_alloc(e, &d_col, slots) || dev_alloc(e, &d_rowl, slots) ||
       dev_alloc(e, &d_psrc, slots) || dev_alloc(e, &d_brk, brk.size()) || dev_alloc(e, &d_slot0, slot0.size()) ||
-      dev_alloc(e, &d_segrow, segrow.size()) || dev_alloc(e, &rc.ubuf, (size_t)2 * rc.npad) ||
+      dev_alloc(e, &d_segrow, segrow.size()) || dev_alloc(e, &rc.ubuf, (size_t)2 * (rc.npad + 4 * 256)) ||
       dev_alloc(e, &rc.flags, (size_t)nwg * 16) || dev_alloc(e, &rc.sbuf, (size_t)2 * nwg * 8)) return HIPENG_ERR_HIP;
 #define UP(dst, src) HIPCHK(hipMemcpyAsync(dst, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, e->stream))
   UP(d_wg, wg); UP(d_col, col); UP(d_rowl, rowl); UP(d_psrc, psrc); UP(d_brk, brk); UP(d_slot0, slot0); UP(d_segrow, segrow);
@@ -1937,7 +2082,7 @@ static int build_resident(hipeng *e) {
   HIPCHK(hipStreamSynchronize(e->stream));       // the sources are locals
   rc.wg = d_wg; rc.col = d_col; rc.rowl = d_rowl; rc.psrc = d_psrc; rc.brk = d_brk; rc.slot0 = d_slot0; rc.segrow = d_segrow;
   e->rc = rc;
-  e->res_lds = ((size_t)rc.npad + RES_TB + RES_MAXROWS + 16 + 5 * 64) * sizeof(double);   // + phase stamps of the TIMELINE build
+  e->res_lds = ((size_t)rc.npad + 4 * 256 + RES_TB + RES_MAXROWS + 16 + 5 * 64 + 48) * sizeof(double);   // + phase stamps of the TIMELINE build
   int rcode = 0;
   switch (E) {
     case 8: rcode = res_set_lds<8>(e->res_lds); break;   case 16: rcode = res_set_lds<16>(e->res_lds); break;

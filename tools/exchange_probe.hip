@@ -4,6 +4,7 @@
 //   mode 0: no exchange (loop + barriers + the emulated row work): the floor
 //   mode 1: data-tagged 16-byte granules {double, tag}, sc1 stores, sc1 sweep until every tag matches
 //   mode 2: sc1 payload (16-byte stores of two doubles), drain, one flag per workgroup, poll flags, sc1 payload loads
+//   mode 3: the tag in the two low mantissa bits of every double (8-byte sc1 stores, sc1 sweep until every word carries it)
 // Every word is checked against its expected value; `uneven` makes some workgroups late on some iterations.
 // build: hipcc -O3 --offload-arch=gfx950 tools/exchange_probe.hip -o tools/exchange_probe
 #include <hip/hip_runtime.h>
@@ -15,6 +16,7 @@
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define AUX_SC1 16
 
 static __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes)
@@ -37,6 +39,7 @@ constexpr int TPB = 512;
 constexpr int E = 16;          // emulated operator entries per thread
 constexpr int KMAX = 24;       // granules per thread per sweep (G <= 512 * KMAX)
 
+template <int MODE>
 __global__ __launch_bounds__(TPB) void k_probe(Args a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // G doubles + TPB partials
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(TPB) void k_probe(Args a)
             long long t0 = wall_clock64();
             while (wall_clock64() - t0 < 150) { }
         }
-        if (a.mode == 1) {
+        if (MODE == 1) {
             __amdgpu_buffer_rsrc_t rs = make_rsrc((const char *)a.buf + (size_t)par * G * 16, (unsigned)G * 16u);
             if (t < a.per) {
                 int j = g * a.per + t;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(TPB) void k_probe(Args a)
                 if (wall_clock64() - t0 > t_limit) { s_fail = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-        } else if (a.mode == 2) {
+        } else if (MODE == 2) {
             __amdgpu_buffer_rsrc_t rs = make_rsrc((const char *)a.buf + (size_t)par * G * 8, (unsigned)G * 8u);
             if (t < a.per / 2) {
                 int j = g * a.per + 2 * t;
@@ -131,13 +134,45 @@ __global__ __launch_bounds__(TPB) void k_probe(Args a)
                     lds[2 * j2] = __hiloint2double((int)r[k].y, (int)r[k].x);
                     lds[2 * j2 + 1] = __hiloint2double((int)r[k].w, (int)r[k].z);
                 }
+        } else if (MODE == 3) {
+            // the tag rides in the two low mantissa bits of every double: no flag, no drain, 8 bytes per value
+            __amdgpu_buffer_rsrc_t rs = make_rsrc((const char *)a.buf + (size_t)par * G * 8, (unsigned)G * 8u);
+            const unsigned tg = tag & 3u;
+            if (t < a.per) {
+                int j = g * a.per + t;
+                double v = expected(j, it);
+                u32x2 w;
+                w.x = ((unsigned)__double2loint(v) & ~3u) | tg; w.y = (unsigned)__double2hiint(v);
+                __builtin_amdgcn_raw_buffer_store_b64(w, rs, j * 8, 0, AUX_SC1);
+            }
+            u32x4 r[KMAX / 2];
+            unsigned pending = 0;
+#pragma unroll
+            for (int k = 0; k < KMAX / 2; ++k) if (t + k * TPB < G / 2) pending |= 1u << k;
+            long long t0 = wall_clock64();
+            while (true) {
+#pragma unroll
+                for (int k = 0; k < KMAX / 2; ++k)
+                    if (pending & (1u << k)) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (t + k * TPB) * 16, 0, AUX_SC1);
+#pragma unroll
+                for (int k = 0; k < KMAX / 2; ++k)
+                    if ((pending & (1u << k)) && (r[k].x & 3u) == tg && (r[k].z & 3u) == tg) {
+                        int j2 = t + k * TPB;
+                        lds[2 * j2] = __hiloint2double((int)r[k].y, (int)(r[k].x & ~3u));
+                        lds[2 * j2 + 1] = __hiloint2double((int)r[k].w, (int)(r[k].z & ~3u));
+                        pending &= ~(1u << k);
+                    }
+                if (!pending) break;
+                asm volatile("" ::: "memory");
+                if (wall_clock64() - t0 > t_limit) { s_fail = 1; break; }
+            }
         } else {
             for (int j = t; j < G; j += TPB) lds[j] = expected(j, it);
         }
         __syncthreads();
         if (s_fail) break;
         // check every word
-        if (a.mode) for (int j = t; j < G; j += TPB) bad += (lds[j] != expected(j, it));
+        if (MODE) for (int j = t; j < G; j += TPB) bad += (lds[j] != expected(j, it));   // expected() values have zero low mantissa bits
         // emulated operator rows: E products per thread from LDS, then a two-level sum
         if (a.work) {
             double s = 0.0;
@@ -176,9 +211,12 @@ int main(int argc, char **argv)
     CK(hipMemcpy(cols, hc.data(), hc.size() * 2, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     size_t lds = (size_t)(G + TPB + 2) * 8;
-    CK(hipFuncSetAttribute((const void *)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)k_probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)k_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)k_probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)k_probe<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int work = 0; work < 2; ++work)
-        for (int mode = 0; mode < 3; ++mode)
+        for (int mode = 0; mode < 4; ++mode)
             for (int uneven = 0; uneven < 2; ++uneven) {
                 if (mode == 0 && uneven) continue;
                 float best = 1e30f; unsigned herr[2] = {0, 0};
@@ -188,7 +226,10 @@ int main(int argc, char **argv)
                     CK(hipMemset(err, 0, 8));
                     Args a{buf, flags, G, per, iters, mode, uneven, work, cols, out, err};
                     CK(hipEventRecord(e0));
-                    hipLaunchKernelGGL(k_probe, dim3(WG), dim3(TPB), lds, 0, a);
+                    if (mode == 0) hipLaunchKernelGGL(k_probe<0>, dim3(WG), dim3(TPB), lds, 0, a);
+                    else if (mode == 1) hipLaunchKernelGGL(k_probe<1>, dim3(WG), dim3(TPB), lds, 0, a);
+                    else if (mode == 2) hipLaunchKernelGGL(k_probe<2>, dim3(WG), dim3(TPB), lds, 0, a);
+                    else hipLaunchKernelGGL(k_probe<3>, dim3(WG), dim3(TPB), lds, 0, a);
                     CK(hipEventRecord(e1));
                     CK(hipEventSynchronize(e1));
                     float ms; CK(hipEventElapsedTime(&ms, e0, e1));

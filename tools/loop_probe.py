@@ -30,6 +30,17 @@ if hasattr(L, "hipeng_timeline"):      # make TIMELINE=1 build: where the time o
     r = s.solve()
     k = L.hipeng_timeline(s.engine(), buf.ctypes.data, buf.size)
     ids = (buf[:k] >> np.uint64(56)).astype(int); ts = (buf[:k] & np.uint64((1 << 56) - 1)).astype(np.int64) * 10e-3   # us
+    wsel = (ids >= 20) & (ids < 60)
+    if wsel.any():           # per-wavefront stamps of one pipelined iteration (relative to wavefront 0 after the exchange)
+        print("  one pipelined iteration, workgroup 0, us after the exchange (rows: after-exchange, products issued, scalars, barrier, update; columns: wavefronts 0..7)")
+        for ph in range(5):
+            row = []
+            for wv in range(8):
+                v = ts[ids == 20 + ph * 8 + wv]
+                v = v[v < 1e4]
+                row.append(v.mean() if v.size else float("nan"))
+            print("   phase %d: " % ph + " ".join("%6.2f" % x for x in row))
+    ids, ts = ids[~wsel], ts[~wsel]
     order = np.argsort(ts, kind="stable"); ids, ts = ids[order], ts[order]
     per = np.diff(ts)
     names = {1: "k_pcg_init", 2: "k_cg_A", 3: "k_cg_B", 4: "k_admm_finalize"}
