@@ -960,6 +960,7 @@ struct ResWG { int r0, nr, cnt, pad; };   // first row, rows (<= RES_MAXROWS), e
 struct ResCtx {
   int nwg, E, npad;                  // workgroups, entries per thread, n rounded up to even
   int pipe;                          // 1: pipelined recurrences where they pass their checks (OSQP_AMD_RESIDENT_PIPE=0: never)
+  int u0_direct;                     // 1: the first product reads u0 from global memory instead of exchanging it
   const ResWG *wg;
   double *val;                       // [nwg][E][RES_PT]: entry t*E + k of the workgroup's row-major list at (k, t)
   const unsigned short *col;         // same layout
@@ -1133,6 +1134,15 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   };
   // rows of K times the vector in LDS: E products per thread, row segments through LDS; the own-row value
   // in the lanes of wavefront 0 (ends with the barrier that makes the segments visible)
+  // u0 = Minv r0 was left in global memory by k_pcg_init (an earlier launch: plain loads see it): no exchange needed
+  auto load_u0 = [&]() __attribute__((always_inline)) {
+    const double2 *src = reinterpret_cast<const double2 *>(c.init_z);
+    const int half = c.n >> 1;
+#pragma unroll 4
+    for (int i2 = t; i2 < half; i2 += RES_TB) { const double2 v = src[i2]; uv[2 * i2] = v.x; uv[2 * i2 + 1] = v.y; }
+    if ((c.n & 1) && t == 0) uv[c.n - 1] = c.init_z[c.n - 1];
+    __syncthreads();
+  };
   auto products_issue = [&]() __attribute__((always_inline)) {
     if (prod) {
       // gathers first (all in flight together; the segment writes below could alias them as far as the compiler knows),
@@ -1167,7 +1177,6 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
       }
     return a;
   };
-  auto products = [&]() __attribute__((always_inline)) -> double { products_issue(); return products_finish(); };
   // Exchange (2): three dot partials per workgroup as {value, tag} granules (the data is the flag); totals in sc[0..2].
   auto scal_exchange = [&](double pg, double pd, double prr) __attribute__((always_inline)) -> bool {
     if (wv == 0) {
@@ -1213,92 +1222,78 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
 
   double gam_old = 0.0, alp_old = 0.0;
   int iters = 0;
-  bool conv = false, bad = false, failed = false, finished = false;
-
-  // ---- phase P: pipelined recurrences (Ghysels-Vanroose): ONE exchange per iteration.  m = Minv w travels with the
-  // partials of (r,u), (w,u), (r,r); every workgroup forms the scalars itself; w, u follow recurrences instead of a
-  // fresh product.  Those recurrences drift on ill-conditioned systems, so: out after 64 iterations, out on any
-  // breakdown, and every solve that claims convergence is checked against the true residual r0 - K (x - x0).
-  // A failed check hands the solve to phase C and switches phase P off until K changes.
-  bool to_check = false;
+  bool conv = false, bad = false, failed = false;
+  // One loop, one copy of each exchange (four inlined copies cost 88 spilled registers).  Modes:
+  //   0  w = K u0 for the pipelined phase           1  pipelined iteration (Ghysels-Vanroose): ONE exchange -- m = Minv w
+  //   2  true-residual check r0 - K (x - x0)           travels with the partials of (r,u), (w,u), (r,r); wavefront 0 forms
+  //   3  Chronopoulos-Gear iteration with a fresh      the scalars while the others multiply; w and u follow recurrences
+  //      product (the recurrences of k_cg_A/k_cg_B)
+  // The pipelined recurrences drift on ill-conditioned systems, so: out after 64 iterations, out on any breakdown, and
+  // every solve that claims convergence is checked against the true residual.  A failed check hands the solve to
+  // mode 3 and switches the pipelined phase off until K changes.
+  int mode = pipe ? 0 : 3;
   int check_why = 0;                   // 0: the recurrence says converged, 1: breakdown / iteration cap, 2: long solve
-  if (pipe) {
-    if (!vec_exchange(u_, 0.0, 0.0, 0.0)) failed = true;
-    else {
-      w_ = products();
-      while (true) {
-        const double m_ = mi * w_;
-        double pg = 0.0, pd = 0.0, prr = 0.0;
-        if (wv == 0) { if (own) { pg = r_ * u_; pd = w_ * u_; prr = r_ * r_; } pg = wave_sum(pg); pd = wave_sum(pd); prr = wave_sum(prr); }
-        if (!vec_exchange(m_, pg, pd, prr)) { failed = true; break; }
-        // K m by wavefronts 1..7 while every wavefront forms the scalars (the same sums in the same order); the
-        // products of the iteration that finds the stop are wasted
-        WTL(0);
-        // K m by wavefronts 1..7 while wavefront 0 (which holds no entries of K) forms the scalars and takes the
-        // step's decisions; its verdict reaches the others through LDS at the barrier.  The products of the iteration
-        // that finds the stop are wasted.
-        products_issue();
-        WTL(1);
-        CgStep cs{};
-        if (wv == 0) {
-          double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  bool have_u0 = rc.u0_direct;         // the vector k_pcg_init left in global memory is still the u of the recurrences
+  while (true) {
+    double val = u_, e0 = 0.0, e1 = 0.0, e2 = 0.0, m_ = 0.0;
+    if (mode == 1) {
+      m_ = mi * w_; val = m_;
+      if (wv == 0) { e0 = wave_sum(own ? r_ * u_ : 0.0); e1 = wave_sum(own ? w_ * u_ : 0.0); e2 = wave_sum(own ? r_ * r_ : 0.0); }
+    } else if (mode == 2) val = x_ - x0_;
+    if (have_u0) { ++nx; tag = ep0 + (unsigned)nx; par = (int)(tag & 1u); load_u0(); have_u0 = false; }   // (a fresh tag for the granules of exchange (2))
+    else if (!vec_exchange(val, e0, e1, e2)) { failed = true; break; }
+    WTL(0);
+    products_issue();
+    WTL(1);
+    CgStep cs{};
+    if (mode == 1 && wv == 0) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) if (lane + 64 * q < nwg) { a0 += tail[4 * (lane + 64 * q)]; a1 += tail[4 * (lane + 64 * q) + 1]; a2 += tail[4 * (lane + 64 * q) + 2]; }
-          const double gam = wave_sum(a0), del = wave_sum(a1), rr = wave_sum(a2);
-          cs = cg_step(rr, gam, del, gam_old, alp_old, tol2, iters, 0, prm, false);
-          gam_old = gam; alp_old = cs.alpha;
-          if (lane == 0) sc[4] = cs.stop ? (cs.conv ? 1.0 : 2.0) : 0.0;
-        }
-        WTL(2);
-        const double n_ = products_finish();
-        const double verdict = sc[4];
-        WTL(3);
-        if (verdict != 0.0) { to_check = true; check_why = verdict == 1.0 ? 0 : 1; break; }
-        ++iters;
-        if (own) {
-          z_ = cs.first ? n_ : (n_ + cs.beta * z_);
-          q_ = cs.first ? m_ : (m_ + cs.beta * q_);
-          s_ = cs.first ? w_ : (w_ + cs.beta * s_);
-          p_ = cs.first ? u_ : (u_ + cs.beta * p_);
-          x_ += cs.alpha * p_;
-          r_ -= cs.alpha * s_;
-          u_ -= cs.alpha * q_;
-          w_ -= cs.alpha * z_;
-        }
-        WTL(4);
-        if (iters >= 64) { to_check = true; check_why = 2; break; }
-      }
+      for (int q = 0; q < 4; ++q) if (lane + 64 * q < nwg) { a0 += tail[4 * (lane + 64 * q)]; a1 += tail[4 * (lane + 64 * q) + 1]; a2 += tail[4 * (lane + 64 * q) + 2]; }
+      const double gam = wave_sum(a0), del = wave_sum(a1), rr = wave_sum(a2);
+      cs = cg_step(rr, gam, del, gam_old, alp_old, tol2, iters, 0, prm, false);
+      gam_old = gam; alp_old = cs.alpha;
+      if (lane == 0) sc[4] = cs.stop ? (cs.conv ? 1.0 : 2.0) : 0.0;
     }
-    if (to_check && !failed) {
-      // true residual of the current iterate
-      if (!vec_exchange(x_ - x0_, 0.0, 0.0, 0.0)) failed = true;
-      else {
-        const double kd = products();
-        const double rt = r0_ - kd;
-        if (!scal_exchange(0.0, 0.0, own ? rt * rt : 0.0)) failed = true;
-        else {
-          const double rrt = sc[2];
-          if (rrt <= 2.0 * tol2) { conv = true; finished = true; }
-          else {
-            // continue from the true residual with fresh directions in phase C; the recurrences are switched off for
-            // this K when they had claimed convergence or broken down (not when the solve was merely long)
-            if (own) { r_ = rt; u_ = mi * rt; }
-            gam_old = 0.0; alp_old = 0.0;
-            if (g == 0 && t == 0 && check_why != 2) st->res_pipe_off = 1;
-          }
-          __syncthreads();          // sc[] is rewritten by the next exchange
-        }
+    WTL(2);
+    const double kx = products_finish();       // own row of K times the exchanged vector
+    WTL(3);
+    if (mode == 0) { w_ = kx; mode = 1; continue; }
+    if (mode == 1) {
+      const double verdict = sc[4];
+      if (verdict != 0.0) { check_why = verdict == 1.0 ? 0 : 1; mode = 2; continue; }   // (the products of this trip are wasted)
+      ++iters;
+      if (own) {
+        z_ = cs.first ? kx : (kx + cs.beta * z_);
+        q_ = cs.first ? m_ : (m_ + cs.beta * q_);
+        s_ = cs.first ? w_ : (w_ + cs.beta * s_);
+        p_ = cs.first ? u_ : (u_ + cs.beta * p_);
+        x_ += cs.alpha * p_;
+        r_ -= cs.alpha * s_;
+        u_ -= cs.alpha * q_;
+        w_ -= cs.alpha * z_;
       }
+      WTL(4);
+      if (iters >= 64) { check_why = 2; mode = 2; }
+      continue;
     }
-  }
-
-  // ---- phase C: Chronopoulos-Gear with a fresh product every iteration (the recurrences of k_cg_A / k_cg_B) ----
-  while (!finished && !failed) {
-    if (!vec_exchange(u_, 0.0, 0.0, 0.0)) { failed = true; break; }
-    w_ = products();
+    if (mode == 2) {
+      const double rt = r0_ - kx;
+      if (!scal_exchange(0.0, 0.0, own ? rt * rt : 0.0)) { failed = true; break; }
+      if (sc[2] <= 2.0 * tol2) { conv = true; break; }
+      // continue from the true residual with fresh directions; the recurrences are switched off for this K when they
+      // had claimed convergence or broken down (not when the solve was merely long)
+      if (own) { r_ = rt; u_ = mi * rt; }
+      gam_old = 0.0; alp_old = 0.0;
+      if (g == 0 && t == 0 && check_why != 2) st->res_pipe_off = 1;
+      __syncthreads();          // sc[] is rewritten by the next exchange
+      mode = 3;
+      continue;
+    }
+    w_ = kx;
     if (!scal_exchange(own ? r_ * u_ : 0.0, own ? w_ * u_ : 0.0, own ? r_ * r_ : 0.0)) { failed = true; break; }
     const double gam = sc[0], del = sc[1], rr = sc[2];
-    const CgStep cs = cg_step(rr, gam, del, gam_old, alp_old, tol2, iters, 0, prm, false);
+    cs = cg_step(rr, gam, del, gam_old, alp_old, tol2, iters, 0, prm, false);
     if (cs.stop) { conv = cs.conv; bad = cs.bad && !cs.conv; break; }
     ++iters; gam_old = gam; alp_old = cs.alpha;
     if (own) {
@@ -2036,7 +2031,8 @@ static int build_resident(hipeng *e) {
     wg[g].nr = rows; wg[g].cnt = (int)cnt;
   }
   const size_t slots = (size_t)nwg * E * RES_PT;
-  const bool fake_col = getenv("OSQP_AMD_RES_FAKECOL") != nullptr;   // timing experiment: conflict-free LDS gathers (results are garbage)
+  bool bank_sched = true;
+  if (const char *x = getenv("OSQP_AMD_RESIDENT_BANKS")) bank_sched = atoi(x) != 0;
   std::vector<unsigned short> col(slots, 0), slot0((size_t)nwg * RES_PT, 0), segrow((size_t)nwg * (RES_MAXROWS + 1), 0);
   std::vector<unsigned char> rowl(slots, 0);
   std::vector<int> psrc(slots, -1);
@@ -2048,17 +2044,62 @@ static int build_resident(hipeng *e) {
     std::vector<int> rowof(w.cnt);
     for (int r = 0; r < w.nr; r++)
       for (int q = Kptr[w.r0 + r] - base; q < Kptr[w.r0 + r + 1] - base; q++) rowof[q] = r;
+    // Order of the entries inside each thread's chunk.  One wave instruction of the product loop gathers 64 doubles from
+    // LDS at the columns of the lanes' k-th entries; random columns pile up to ~6 lanes on one of the 32 bank pairs.
+    // A chunk that lies inside one row may be summed in any order, so its entries are dealt to the E slots such that
+    // each slot spreads over the bank pairs (greedy deal + pairwise swaps; deterministic).
+    std::vector<int> ord((size_t)RES_PT * E, -1);
+    for (int le = 0; le < w.cnt; le++) ord[le] = le;
+    if (bank_sched)
+    for (int wq = 0; wq < RES_PT / 64; wq++) {
+      int cntb[64][32];                           // [slot][bank pair] over the 64 lanes of this wavefront
+      for (int k = 0; k < E; k++) for (int b = 0; b < 32; b++) cntb[k][b] = 0;
+      bool freec[64];
+      for (int l = 0; l < 64; l++) {
+        const int t = wq * 64 + l, a = t * E;
+        freec[l] = a + E <= w.cnt && rowof[a] == rowof[a + E - 1];
+        if (!freec[l]) for (int k = 0; k < E && a + k < w.cnt; k++) cntb[k][Kcol[base + a + k] & 31]++;
+      }
+      for (int k = 0; k < E; k++)                 // deal: slot by slot, every free lane gives the entry whose bank pair is emptiest
+        for (int l = 0; l < 64; l++) {
+          if (!freec[l]) continue;
+          const int a = (wq * 64 + l) * E;
+          int best = k, bc = 1 << 30;
+          for (int q = k; q < E; q++) { const int c = cntb[k][Kcol[base + ord[a + q]] & 31]; if (c < bc) { bc = c; best = q; } }
+          std::swap(ord[a + k], ord[a + best]);
+          cntb[k][Kcol[base + ord[a + k]] & 31]++;
+        }
+      auto slot_max = [&](int k) { int mx = 0; for (int b = 0; b < 32; b++) mx = std::max(mx, cntb[k][b]); return mx; };
+      for (int pass = 0; pass < 4; pass++)        // swaps between two slots of one lane that lower the two slots' maxima
+        for (int l = 0; l < 64; l++) {
+          if (!freec[l]) continue;
+          const int a = (wq * 64 + l) * E;
+          for (int k = 0; k < E; k++) {
+            const int bk = Kcol[base + ord[a + k]] & 31;
+            if (cntb[k][bk] < slot_max(k) || cntb[k][bk] <= 2) continue;
+            for (int q = 0; q < E; q++) {
+              if (q == k) continue;
+              const int bq = Kcol[base + ord[a + q]] & 31;
+              if (bq == bk) continue;
+              const int before = slot_max(k) + slot_max(q);
+              cntb[k][bk]--; cntb[k][bq]++; cntb[q][bq]--; cntb[q][bk]++;
+              if (slot_max(k) + slot_max(q) < before) { std::swap(ord[a + k], ord[a + q]); break; }
+              cntb[k][bk]++; cntb[k][bq]--; cntb[q][bq]++; cntb[q][bk]--;
+            }
+          }
+        }
+    }
     int nseg = 0, next_row = 0;
     for (int t = 0; t < RES_PT; t++) {
       slot0[(size_t)g * RES_PT + t] = (unsigned short)nseg;
       unsigned long long b = 0;
       for (int k = 0; k < E; k++) {
-        const int le = t * E + k;
-        if (le >= w.cnt) break;
+        if (t * E + k >= w.cnt) break;
+        const int le = ord[t * E + k];
         const size_t sl = ((size_t)g * E + k) * RES_PT + t;
-        col[sl] = fake_col ? (unsigned short)((t + 64 * k) % n) : (unsigned short)Kcol[base + le]; rowl[sl] = (unsigned char)rowof[le]; psrc[sl] = Kps[base + le];
+        col[sl] = (unsigned short)Kcol[base + le]; rowl[sl] = (unsigned char)rowof[le]; psrc[sl] = Kps[base + le];
         while (next_row <= rowof[le]) segrow[(size_t)g * (RES_MAXROWS + 1) + next_row++] = (unsigned short)nseg;   // first segment of the row
-        const bool last = k == E - 1 || le + 1 >= w.cnt || rowof[le + 1] != rowof[le];
+        const bool last = k == E - 1 || t * E + k + 1 >= w.cnt || rowof[ord[t * E + k + 1]] != rowof[le];
         if (last) { b |= 1ull << k; nseg++; }
       }
       brk[(size_t)g * RES_PT + t] = b;
@@ -2070,6 +2111,8 @@ static int build_resident(hipeng *e) {
   rc.nwg = nwg; rc.E = E; rc.npad = (n + 1) & ~1;
   rc.pipe = 1;
   if (const char *x = getenv("OSQP_AMD_RESIDENT_PIPE")) rc.pipe = atoi(x) != 0;
+  rc.u0_direct = 1;
+  if (const char *x = getenv("OSQP_AMD_RESIDENT_U0")) rc.u0_direct = atoi(x) != 0;
   ResWG *d_wg = nullptr; unsigned short *d_col = nullptr, *d_slot0 = nullptr, *d_segrow = nullptr; unsigned char *d_rowl = nullptr;
   int *d_psrc = nullptr; unsigned long long *d_brk = nullptr;
   if (dev_alloc(e, &d_wg, wg.size()) || dev_alloc(e, &rc.val, slots) || dev_alloc(e, &d_col, slots) || dev_alloc(e, &d_rowl, slots) ||
