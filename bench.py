@@ -69,6 +69,53 @@ def kernel_roofline(solver, reps=300):
                          gbs=by.value / (us.value * 1e-6) / 1e9))
     pair = C.c_double()
     assert L.hipeng_time_kernel(solver.engine(), 6, reps, C.byref(pair)) == 0       # A then B, as the loop launches them
+    n, m = solver.n, solver.m
+    # SURVEY 8(d): algorithmic bytes of one PCG iteration, B_pcg = 2 S_A + S_P + 8 (10 n + 3 m)
+    b_pcg = 2 * (solver.nnzA * 12 + (m + 1) * 4) + (solver.nnzP * 12 + (n + 1) * 4) + 8 * (10 * n + 3 * m)
+    per_step = dict(all_kernels=[dict(kernel=r["kernel"], usec=round(r["usec"], 3), gbs=round(r["gbs"], 2)) for r in rows],
+                    pcg_iteration=dict(usec=round(pair.value, 3), survey_B_pcg_bytes=b_pcg,
+                                       gbs=round(b_pcg / pair.value / 1e3, 2), frac=round(b_pcg / pair.value / 1e3 / HBM_PEAK_GBS, 5),
+                                       note="one PCG iteration = k_cg_A + k_cg_B in loop order; bytes = SURVEY 8(d) B_pcg"))
+    L.hipeng_resident_info.restype = C.c_int
+    L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    info = (C.c_longlong * 8)()
+    assert L.hipeng_resident_info(solver.engine(), info) == 0
+    if info[1]:
+        # Resident engine: ONE launch of k_pcg_resident is the whole linear solve of an ADMM iteration (K in registers,
+        # the PCG iterations exchange vectors inside the launch).  Its duration: HIP events around `reps` graph-captured
+        # repetitions of [k_pcg_init, k_pcg_resident] on the engine's stream, minus k_pcg_init timed the same way.
+        # Units of one launch: the PCG iterations it ran (read back from the device); bytes per unit: SURVEY 8(d) B_pcg.
+        reps2 = 100
+        t_pair = C.c_double(); t_init = C.c_double()
+        assert L.hipeng_time_kernel(solver.engine(), 8, reps2, C.byref(t_pair)) == 0
+        assert L.hipeng_time_kernel(solver.engine(), 5, reps2, C.byref(t_init)) == 0
+        assert L.hipeng_resident_info(solver.engine(), info) == 0
+        its = int(info[6])
+        us = t_pair.value - t_init.value
+        gbs = b_pcg * its / us / 1e3
+        traffic, src = None, "profiles/r02_config2_resident_pmc_and_durations.json"
+        try:
+            prof = json.load(open(os.path.join(ROOT, src)))
+            if (n, m) == (10000, 20000):
+                k = [v for kk, v in prof["kernels"].items() if kk.startswith("k_pcg_resident")][0]
+                traffic = float(k["traffic_bytes_corrected"])
+        except Exception:
+            traffic = None
+        return dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 5),
+                    traffic=traffic, kernel="k_pcg_resident",
+                    traffic_note="HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes (%s); "
+                                 "the factor 2 on FETCH_SIZE is measured in profiles/r02_fetch_calibration.json" % src,
+                    bytes_per_launch=b_pcg * its, usec_per_launch=round(us, 3), pcg_iterations_per_launch=its,
+                    usec_per_pcg_iteration=round(us / max(its, 1), 3),
+                    resident=dict(nnzK=int(info[4]), workgroups=int(info[3]), entries_per_thread=int(info[2]), lds_bytes=int(info[5]),
+                                  register_bytes_of_K=int(info[4]) * 10),
+                    note="one launch = one linear solve: K = P + sigma I + A' rho A (%d entries) sits in the register files of %d CUs, "
+                         "each PCG iteration exchanges one n-vector between the workgroups inside the launch; duration = (%d graph-captured "
+                         "[k_pcg_init, k_pcg_resident] pairs - the same count of k_pcg_init) / %d, every repetition the same solve of %d PCG "
+                         "iterations; algorithmic bytes = SURVEY 8(d) B_pcg x iterations (what the launch-per-step kernels stream for the same "
+                         "work); the kernel is bound by the latency of the in-launch exchanges (tools/exchange_probe.hip), not by HBM"
+                         % (int(info[4]), int(info[3]), reps2, reps2, its),
+                    launch_per_step_kernels=per_step)
     dom = max(rows, key=lambda r: r["usec"])
     # HBM-side traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate
     # runs, same workload), corrected as the calibration run prescribes: bytes = 2 x FETCH_SIZE + WRITE_SIZE
@@ -82,9 +129,6 @@ def kernel_roofline(solver, reps=300):
             traffic = float(k["traffic_bytes_corrected"])
     except Exception:
         traffic = None
-    # SURVEY 8(d): algorithmic bytes of one PCG iteration, B_pcg = 2 S_A + S_P + 8 (10 n + 3 m)
-    n, m = solver.n, solver.m
-    b_pcg = 2 * (solver.nnzA * 12 + (m + 1) * 4) + (solver.nnzP * 12 + (n + 1) * 4) + 8 * (10 * n + 3 * m)
     return dict(bound="hbm", achieved=round(dom["gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(dom["gbs"] / HBM_PEAK_GBS, 5), traffic=traffic, kernel=dom["kernel"],
                 traffic_note="HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes (%s); "
@@ -92,11 +136,7 @@ def kernel_roofline(solver, reps=300):
                 bytes_per_launch=dom["bytes"], usec_per_launch=round(dom["usec"], 3),
                 note="launch-to-launch period of %d graph-captured back-to-back launches (includes the "
                      "dependent-kernel boundary); the 8 MB working set is L2/Infinity-Cache resident" % reps,
-                all_kernels=[dict(kernel=r["kernel"], usec=round(r["usec"], 3), gbs=round(r["gbs"], 2))
-                             for r in rows],
-                pcg_iteration=dict(usec=round(pair.value, 3), survey_B_pcg_bytes=b_pcg,
-                                   gbs=round(b_pcg / pair.value / 1e3, 2), frac=round(b_pcg / pair.value / 1e3 / HBM_PEAK_GBS, 5),
-                                   note="one PCG iteration = k_cg_A + k_cg_B in loop order; bytes = SURVEY 8(d) B_pcg"))
+                **per_step)
 
 
 def other_configs(eps):

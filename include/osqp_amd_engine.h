@@ -138,11 +138,20 @@ int hipeng_spmv(hipeng *e, int which, const c_float *x, c_float *y);
 int hipeng_spmv_dev(hipeng *e, int which, const c_float *d_x, c_float *d_y);
 /* Time `reps` back-to-back launches of one hot kernel on the engine stream with
  * HIP events; returns average microseconds per launch in *usec.
- * which = 0: K1 (A p), 1: K2 ([P|A'] apply), 2: K3 (vector update + dots). */
+ * which = 0: k_cg_A, 1: k_cg_B, 3 / 4: k_cg_A update-only / apply-only (split mode), 5: k_pcg_init,
+ * 6: k_cg_A + k_cg_B in loop order, 7: an empty dependent launch, 8: k_pcg_init + k_pcg_resident (the
+ * right-hand side and the whole linear solve of one ADMM iteration; resident engines only). */
 int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec);
 /* Algorithmic bytes of one launch of the kernels above. */
 int hipeng_kernel_bytes(hipeng *e, int which, double *bytes);
 int hipeng_is_split(hipeng *e);   /* k_cg_A as two launches (update-only + apply-only)? */
+/* Resident PCG (the reduced matrix K = P + sigma I + A' rho A held in registers, one launch per linear
+ * solve; engine.hip, k_pcg_resident).  out[0] structures built, [1] in use, [2] entries of K per thread,
+ * [3] workgroups, [4] nnz(K), [5] LDS bytes per workgroup, [6] PCG iterations of the most recent linear
+ * solve, [7] pipelined recurrences switched off for the current K. */
+int hipeng_resident_info(hipeng *e, long long out[8]);
+/* For the tests: K as the resident kernel holds it, as triplets; returns nnz(K) or a negative code. */
+long long hipeng_resident_dump(hipeng *e, int *row, int *col, double *val, long long cap);
 
 #ifdef __cplusplus
 }

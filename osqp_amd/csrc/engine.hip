@@ -1962,20 +1962,23 @@ static void launch_resident(hipeng *e) {
 }
 
 // Returns 0 (with e->res_on set when the problem qualifies) or a HIPENG error.  Not qualifying is not an error.
+#define RES_NO(why) do { if (e->trace) fprintf(stderr, "[osqp_amd] resident PCG not used: %s\n", why); return 0; } while (0)
 static int build_resident(hipeng *e) {
   e->res_on = e->res_use = false;
   const int n = e->n;
   int want = 1, min_n = 256;
   if (const char *x = getenv("OSQP_AMD_RESIDENT")) want = atoi(x);
   if (const char *x = getenv("OSQP_AMD_RESIDENT_MIN_N")) min_n = atoi(x);
-  if (!want || n < min_n || n > RES_MAXN || !e->dP_blks.empty() || !e->hrows.empty() || e->A.blk.size() > (size_t)e->A.nwave) return 0;
+  if (!want) RES_NO("OSQP_AMD_RESIDENT=0");
+  if (n < min_n || n > RES_MAXN) RES_NO("n outside [OSQP_AMD_RESIDENT_MIN_N, 16384]");
+  if (!e->hrows.empty() || e->A.nwave < (int)e->A.blk.size()) RES_NO("A has rows of 8192 or more entries");   // (their outer products alone overflow the register files)
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, e->device));
   const int nwg = std::min(256, prop.multiProcessorCount);
-  if ((long long)nwg * RES_MAXROWS < n || prop.sharedMemPerBlock < 64 * 1024) return 0;
+  if ((long long)nwg * RES_MAXROWS < n || prop.sharedMemPerBlock < 64 * 1024) RES_NO("too few CUs or too little LDS");
   const HostMat &M = e->M, &A = e->A;
   for (int i = 0; i < n; i++)
-    for (int k = M.split[i] + 1; k < M.rowptr[i + 1]; k++) if (M.col[k] <= M.col[k - 1]) return 0;   // the merge in k_form_K wants ascending rows
+    for (int k = M.split[i] + 1; k < M.rowptr[i + 1]; k++) if (M.col[k] <= M.col[k - 1]) RES_NO("a column of A is not sorted by row (or repeats one)");   // the merge in k_form_K wants ascending rows
   // pattern of K, row by row (sorted), with the slot of P(i,j) in M
   const size_t cap_total = (size_t)nwg * RES_PT * 64;
   std::vector<int> Kptr(n + 1, 0), Kcol, Kps, mark(n, -1), pslot(n, -1);
@@ -1987,14 +1990,14 @@ static int build_resident(hipeng *e) {
     for (int k = M.rowptr[i]; k < M.split[i]; k++) {
       const int j = M.col[k];
       add(j);
-      if (pslot[j] != -1) return 0;                 // a repeated entry of P: keep the general path
+      if (pslot[j] != -1) RES_NO("P repeats an entry");
       pslot[j] = k;
     }
     for (int k = M.split[i]; k < M.rowptr[i + 1]; k++) {
       const int row = M.col[k] - n;
       for (int q = A.rowptr[row]; q < A.rowptr[row + 1]; q++) add(A.col[q]);
     }
-    if (Kcol.size() > cap_total) return 0;
+    if (Kcol.size() > cap_total) RES_NO("K has more entries than the register files hold");
     std::sort(Kcol.begin() + start, Kcol.end());
     Kps.resize(Kcol.size());
     for (size_t q = start; q < Kcol.size(); q++) Kps[q] = pslot[Kcol[q]];
@@ -2014,12 +2017,12 @@ static int build_resident(hipeng *e) {
   };
   long long lo = 1, hi = std::max<long long>(nnzK, 1);
   for (int i = 0; i < n; i++) lo = std::max<long long>(lo, Kptr[i + 1] - Kptr[i]);
-  if (packs(hi) > nwg) return 0;
+  if (packs(hi) > nwg) RES_NO("more than 64 rows per workgroup");
   while (lo < hi) { const long long mid = (lo + hi) / 2; if (packs(mid) <= nwg) hi = mid; else lo = mid + 1; }
   const long long C = lo;
   int E = 0;
   for (int cand : RES_E_LIST) if ((long long)cand * RES_PT >= C) { E = cand; break; }
-  if (!E) return 0;
+  if (!E) RES_NO("a row block of K exceeds 448 x 64 entries");
   std::vector<ResWG> wg(nwg, ResWG{n, 0, 0, 0});
   {
     int g = 0, rows = 0; long long cnt = 0; wg[0].r0 = 0;
@@ -2845,9 +2848,15 @@ extern "C" int hipeng_spmv_dev(hipeng *e, int which, const double *d_x, double *
 }
 
 extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) {
-  if (!e || !usec || reps <= 0 || which < 0 || which > 7) return HIPENG_ERR_ARG;
+  if (!e || !usec || reps <= 0 || which < 0 || which > 8) return HIPENG_ERR_ARG;
+  if (which == 8 && !e->res_use) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
+  std::unique_lock<std::mutex> lease;
+  if (which == 8) lease = std::unique_lock<std::mutex>(g_res_mu[e->device & 15]);
   auto one = [&](int it) {
+    // the first two kernels of a resident ADMM iteration: right-hand side + start residual, then the whole linear solve
+    // (without k_admm_finalize the iterates do not move: every repetition solves the same system from the same start)
+    if (which == 8) { launch_init(e, 1); launch_resident(e); return; }
     if (which == 5) { launch_init(e, 1); return; }   // first kernel of an ADMM iteration
     if (which == 6) { launch_pcg_iter(e, it, 4); return; }   // one whole PCG iteration (all its launches, in loop order)
 
@@ -2894,6 +2903,42 @@ extern "C" long long hipeng_timeline(hipeng *e, unsigned long long *out, long lo
 
 // 1 if the vector update and the operator apply of k_cg_A run as two launches (A dominated by long rows)
 extern "C" int hipeng_is_split(hipeng *e) { return e && e->split ? 1 : 0; }
+
+// Resident PCG: out[0] structures built, [1] in use, [2] entries of K per thread, [3] workgroups, [4] nnz(K),
+// [5] LDS bytes per workgroup, [6] PCG iterations of the most recent linear solve, [7] pipelined phase switched off for this K
+extern "C" int hipeng_resident_info(hipeng *e, long long out[8]) {
+  if (!e || !out) return HIPENG_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  State s;
+  if (read_state(e, &s)) return HIPENG_ERR_HIP;
+  out[0] = e->res_on; out[1] = e->res_use; out[2] = e->rc.E; out[3] = e->rc.nwg; out[4] = e->res_nnz; out[5] = (long long)e->res_lds;
+  out[6] = std::max(s.iters[0], s.iters[1]); out[7] = s.res_pipe_off;
+  return 0;
+}
+
+// Resident PCG, for the tests: the rows of K as the resident kernel holds them.  row/col/val receive nnz(K) triplets
+// (row-major inside each workgroup's block, in the order the threads hold them); returns the count or a negative code.
+extern "C" long long hipeng_resident_dump(hipeng *e, int *row, int *col, double *val, long long cap) {
+  if (!e || !e->res_on || !row || !col || !val) return HIPENG_ERR_ARG;
+  if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) return HIPENG_ERR_HIP;
+  const ResCtx &rc = e->rc;
+  const size_t slots = (size_t)rc.nwg * rc.E * RES_PT;
+  std::vector<double> v(slots); std::vector<unsigned short> cc(slots); std::vector<unsigned char> rl(slots); std::vector<ResWG> wg(rc.nwg);
+  if (hipMemcpy(v.data(), rc.val, slots * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(cc.data(), rc.col, slots * sizeof(unsigned short), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(rl.data(), rc.rowl, slots, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(wg.data(), rc.wg, wg.size() * sizeof(ResWG), hipMemcpyDeviceToHost) != hipSuccess) return HIPENG_ERR_HIP;
+  long long k = 0;
+  for (int g = 0; g < rc.nwg; g++)
+    for (int t = 0; t < RES_PT; t++)
+      for (int q = 0; q < rc.E; q++) {
+        if (t * rc.E + q >= wg[g].cnt) break;
+        const size_t sl = ((size_t)g * rc.E + q) * RES_PT + t;
+        if (k >= cap) return HIPENG_ERR_ARG;
+        row[k] = wg[g].r0 + rl[sl]; col[k] = cc[sl]; val[k] = v[sl]; k++;
+      }
+  return k;
+}
 
 extern "C" int hipeng_kernel_bytes(hipeng *e, int which, double *bytes) {
   if (!e || !bytes) return HIPENG_ERR_ARG;

@@ -1,0 +1,198 @@
+"""Resident PCG (engine.hip: k_form_K, k_pcg_resident): the reduced matrix K = P + sigma I + A' diag(rho) A held in
+registers and the whole linear solve of an ADMM iteration in one launch.  Checks: K itself against scipy, the three
+modes of the kernel (pipelined, pipelined handed over after a failed true-residual check, Chronopoulos-Gear only)
+against the oracle through the C ABI, problems far below the size the mode is meant for, and two processes sharing
+the GPU (a resident launch that finds CUs taken gives up and the engine continues with the launch-per-step kernels)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+class _env:
+    def __init__(self, **kw): self.kw = kw
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = str(v)
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+def _info(solver):
+    import osqp_amd
+    L = osqp_amd.lib()
+    L.hipeng_resident_info.restype = C.c_int
+    L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    out = (C.c_longlong * 8)()
+    assert L.hipeng_resident_info(solver.engine(), out) == 0
+    return dict(built=out[0], in_use=out[1], E=out[2], nwg=out[3], nnzK=out[4], lds=out[5], last_iters=out[6], pipe_off=out[7])
+
+
+def _qp(n, m, seed, eq=0, dens=0.02):
+    rng = np.random.default_rng(seed)
+    A = sparse.random(m, n, density=dens, random_state=seed, data_rvs=rng.standard_normal, format="csc")
+    A = (A + sparse.csc_matrix((np.ones(min(m, n)), (np.arange(min(m, n)), np.arange(min(m, n)))), shape=(m, n))).tocsc()
+    B = sparse.random(n, n, density=dens, random_state=seed + 1, data_rvs=rng.standard_normal, format="csc")
+    P = (B @ B.T + 0.05 * sparse.eye(n)).tocsc()
+    q = rng.standard_normal(n)
+    x0 = rng.standard_normal(n)
+    l = A @ x0 - rng.uniform(0.1, 1, m); u = A @ x0 + rng.uniform(0.1, 1, m)
+    if eq: l[:eq] = u[:eq]
+    return dict(P=P, q=q, A=A, l=l, u=u)
+
+
+def test_resident_K_is_P_plus_sigma_plus_AtRhoA(gpu_lib):
+    """k_form_K: every entry of K against scipy (unscaled problem, so the engine's matrices are the caller's), the
+    pattern complete, and K symmetric to the bit (both triangles are summed in the same order)."""
+    import osqp_amd
+    pb = _qp(700, 1100, 3, eq=150)
+    s = osqp_amd.OSQP().setup(**pb, scaling=0, rho=0.3, sigma=1e-6, adaptive_rho=0)
+    inf = _info(s)
+    assert inf["built"] and inf["in_use"] and inf["nwg"] > 0 and inf["E"] >= 8
+    L = osqp_amd.lib()
+    L.hipeng_resident_dump.restype = C.c_longlong
+    L.hipeng_resident_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+    nnz = int(inf["nnzK"])
+    row = np.zeros(nnz, dtype=np.int32); col = np.zeros(nnz, dtype=np.int32); val = np.zeros(nnz)
+    assert L.hipeng_resident_dump(s.engine(), row.ctypes.data, col.ctypes.data, val.ctypes.data, nnz) == nnz
+    n, m = 700, 1100
+    K = sparse.coo_matrix((val, (row, col)), shape=(n, n)).toarray()
+    w = s.work
+    rho = np.ctypeslib.as_array(w.rho_vec, shape=(m,)).copy()
+    assert set(np.round(rho / 0.3, 6)) == {1.0, 1000.0}                  # equality rows carry 1e3 rho
+    Pf = pb["P"].toarray()
+    Pf = np.triu(Pf) + np.triu(Pf, 1).T
+    A = pb["A"].toarray()
+    Kref = Pf + 1e-6 * np.eye(n) + A.T @ (rho[:, None] * A)
+    assert np.abs(K - Kref).max() <= 1e-13 * np.abs(Kref).max()
+    assert np.array_equal(K, K.T)
+    # every structural non-zero of the reference has a slot
+    pat = sparse.coo_matrix((np.ones(nnz), (row, col)), shape=(n, n)).toarray() > 0
+    assert not ((np.abs(Kref) > 0) & ~pat).any()
+    # and the triplets are unique
+    assert len(set(zip(row.tolist(), col.tolist()))) == nnz
+
+
+@pytest.mark.parametrize("pipe", [1, 0])
+def test_resident_modes_match_oracle(gpu_lib, oracle_mod, pipe):
+    """Mid-size QPs with equality rows, with and without the pipelined phase: same iteration count, rho updates and
+    status as the oracle's direct solve; x, y to 1e-6, objective to 1e-8 (the bars of the launch-per-step path)."""
+    import osqp_amd
+    for seed, (n, m, eq) in enumerate([(400, 600, 0), (900, 700, 200), (1500, 300, 40)]):
+        pb = _qp(n, m, 10 + seed, eq=eq)
+        kw = dict(eps_abs=1e-5, eps_rel=1e-5, adaptive_rho_interval=25)
+        with _env(OSQP_AMD_RESIDENT_PIPE=pipe):
+            sg = osqp_amd.OSQP().setup(**pb, **kw)
+        so = oracle_mod.OracleOSQP().setup(**pb, **kw)
+        assert _info(sg)["in_use"]
+        rg, ro = sg.solve(), so.solve()
+        assert rg.info.status == ro.info.status == "solved"
+        assert rg.info.iter == ro.info.iter and rg.info.rho_updates == ro.info.rho_updates
+        assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
+        assert abs(rg.info.obj_val - ro.info.obj_val) <= 1e-8 * max(1.0, abs(ro.info.obj_val))
+        # new q, bounds, then a warm-started solve
+        q2 = pb["q"] * 1.1
+        sg.update(q=q2); so.update(q=q2)
+        rg, ro = sg.solve(), so.solve()
+        assert rg.info.iter == ro.info.iter and _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
+        assert _info(sg)["in_use"]
+
+
+def test_resident_hands_ill_conditioned_solves_to_the_robust_recurrences(gpu_lib, oracle_mod):
+    """cond(K) ~ 1e7 at a tight tolerance: the pipelined recurrences stall above the stop there (their residual drifts
+    from the true one).  Every pipelined solve is checked against r0 - K (x - x0); the failed check continues the solve
+    with Chronopoulos-Gear and switches the pipelined phase off for this K.  Result: the oracle's trajectory."""
+    import osqp_amd
+    rng = np.random.default_rng(7)
+    n, m = 320, 200
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    P = sparse.csc_matrix(Q @ np.diag(np.logspace(-5, 1, n)) @ Q.T)
+    P = ((P + P.T) * 0.5).tocsc()
+    A = sparse.random(m, n, density=0.05, random_state=2, data_rvs=rng.standard_normal, format="csc")
+    x0 = rng.standard_normal(n)
+    pb = dict(P=P, q=rng.standard_normal(n), A=A, l=A @ x0 - 0.5, u=A @ x0 + 0.5)
+    kw = dict(eps_abs=1e-7, eps_rel=1e-7, max_iter=4000)
+    sg = osqp_amd.OSQP().setup(**pb, **kw); so = oracle_mod.OracleOSQP().setup(**pb, **kw)
+    assert _info(sg)["in_use"]
+    rg, ro = sg.solve(), so.solve()
+    assert rg.info.status == ro.info.status == "solved"
+    assert rg.info.iter == ro.info.iter
+    assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-5
+    assert _info(sg)["in_use"]           # still resident: the hand-over happens inside the launch
+
+
+def test_resident_on_tiny_problems(gpu_lib, oracle_mod):
+    """Far below the size the mode is meant for (most workgroups own no row): OSQP_AMD_RESIDENT_MIN_N=1."""
+    import osqp_amd
+    for seed, (n, m) in enumerate([(2, 3), (7, 5), (40, 90), (130, 61)]):
+        pb = _qp(n, m, 30 + seed, eq=min(2, m), dens=0.3)
+        with _env(OSQP_AMD_RESIDENT_MIN_N=1):
+            sg = osqp_amd.OSQP().setup(**pb, eps_abs=1e-6, eps_rel=1e-6)
+        assert _info(sg)["in_use"]
+        so = oracle_mod.OracleOSQP().setup(**pb, eps_abs=1e-6, eps_rel=1e-6)
+        rg, ro = sg.solve(), so.solve()
+        assert rg.info.status == ro.info.status and rg.info.iter == ro.info.iter
+        assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
+
+
+def test_resident_off_by_environment_and_for_large_n(gpu_lib):
+    import osqp_amd
+    pb = _qp(400, 300, 50)
+    with _env(OSQP_AMD_RESIDENT=0):
+        s = osqp_amd.OSQP().setup(**pb)
+    assert not _info(s)["built"]
+    r0 = s.solve()
+    s1 = osqp_amd.OSQP().setup(**pb)
+    r1 = s1.solve()
+    assert _info(s1)["in_use"]
+    # two different linear solvers, one ADMM trajectory
+    assert r0.info.iter == r1.info.iter and _rel(r0.x, r1.x) < 1e-7 and _rel(r0.y, r1.y) < 1e-7
+
+
+_WORKER = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import osqp_amd
+from osqp_amd.problems import random_sparse_qp
+pb = random_sparse_qp(2000, 4000, seed=4)
+s = osqp_amd.OSQP().setup(**pb, eps_abs=1e-5, eps_rel=1e-5)
+out = []
+for k in range(12):
+    s.update(q=pb["q"] * (1.0 + 0.05 * k))
+    r = s.solve()
+    out.append(dict(status=r.info.status, iter=int(r.info.iter), obj=float(r.info.obj_val), x0=float(r.x[0]), xs=float(np.abs(r.x).sum())))
+print(json.dumps(out))
+"""
+
+
+def test_two_processes_share_the_gpu(gpu_lib):
+    """A resident launch needs every CU; a second process's launches take some.  Whatever the interleaving does --
+    launches that wait for each other's workgroups give up after 20 ms and the engine carries on with the
+    launch-per-step kernels -- both processes must return the same solutions as a process running alone."""
+    code = _WORKER % ROOT
+    alone = json.loads(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, check=True).stdout.strip().splitlines()[-1])
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+        got = json.loads(so.strip().splitlines()[-1])
+        for a, b in zip(alone, got):
+            assert b["status"] == a["status"] == "solved" and b["iter"] == a["iter"]
+            assert abs(b["obj"] - a["obj"]) <= 1e-8 * max(1.0, abs(a["obj"]))
+            assert abs(b["xs"] - a["xs"]) <= 1e-7 * a["xs"]
