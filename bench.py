@@ -88,9 +88,9 @@ def kernel_roofline(solver, reps=300):
         reps2 = 100
         t_pair = C.c_double(); t_init = C.c_double()
         assert L.hipeng_time_kernel(solver.engine(), 8, reps2, C.byref(t_pair)) == 0
-        assert L.hipeng_time_kernel(solver.engine(), 5, reps2, C.byref(t_init)) == 0
         assert L.hipeng_resident_info(solver.engine(), info) == 0
-        its = int(info[6])
+        its = int(info[6])                       # (k_pcg_init resets the count: read it before timing that kernel alone)
+        assert L.hipeng_time_kernel(solver.engine(), 5, reps2, C.byref(t_init)) == 0
         us = t_pair.value - t_init.value
         gbs = b_pcg * its / us / 1e3
         traffic, src = None, "profiles/r02_config2_resident_pmc_and_durations.json"

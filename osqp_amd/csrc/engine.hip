@@ -112,6 +112,7 @@ struct State {
   int    res_fail;         // resident PCG: a wait timed out (workgroups not co-resident); the host falls back to the launch-per-step path
   int    res_pipe_off;     // resident PCG: the pipelined recurrences failed a true-residual check for this K (k_form_K clears it)
   int    res_ver_cnt;      // resident PCG: solves since K last changed (which of them are checked: k_pcg_resident)
+  int    res_dbg[4];       // resident PCG, first timed-out wait: 1 = flags / 2 = granules, exchange number, waiting workgroup, first missing workgroup
 };
 
 struct Params {          // mutable scalars (host writes, kernels read)
@@ -965,42 +966,74 @@ struct ResCtx {
   double *val;                       // [nwg][E][RES_PT]: entry t*E + k of the workgroup's row-major list at (k, t)
   const unsigned short *col;         // same layout
   const unsigned char *rowl;         // same layout: local row of the entry
-  const int *psrc;                   // same layout: slot in M of P(i,j), -1 if none
+  const int *krp, *kcj, *kps, *kdst; // K row by row for k_form_K: row pointers (n + 1), column, slot in M of P(i,j) (-1: none), slot in val
   const unsigned long long *brk;     // [nwg][RES_PT]: bit k set = entry k ends a row segment of this thread
   const unsigned short *slot0;       // [nwg][RES_PT]: first segment slot of the thread
   const unsigned short *segrow;      // [nwg][RES_MAXROWS + 1]: first segment slot of each local row
   double *ubuf;                      // 2 x (npad + 4 * 256) doubles (parity of the tag): the vector, then 4 doubles per workgroup
   unsigned *flags;                   // nwg x 16 words (one 64-byte line each)
-  double *sbuf;                      // 2 x nwg x 4 granules {double, tag}
+  double *sbuf;                      // 2 x nwg x 4 slots of 16 bytes: {low word, tag, high word, tag} of one double
 };
 
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const void *p, size_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
 
-// K values in the resident layout.  K_ij = P_ij + sigma [i == j] + sum_k rho_k A_ki A_kj: the sum runs over the rows k
-// that columns i and j of A share (two sorted lists: the A' parts of rows i and j of M), in ascending k -- the same
-// order for (i,j) and (j,i), so K is symmetric to the bit.
+// K values in the resident layout.  K_ij = P_ij + sigma [i == j] + sum_k rho_k (A_ki A_kj): the sum runs over the rows k
+// of A that column i reaches, in ascending k -- the same order and the same products for (i,j) and (j,i), so K is
+// symmetric to the bit.  One wavefront per row i of K: each lane keeps up to four entries (i, j) of the row; the
+// wavefront walks the rows k of A that column i touches (the A' part of row i of M) and broadcasts their entries
+// (k, j') lane by lane; a lane whose j equals j' adds rho_k A_ki A_kj'.  All loads are wavefront-uniform or coalesced:
+// 25 us for the 2.09 M entries of config 2 (a two-list merge per entry took 390 us on dependent scattered loads).
+__device__ __forceinline__ int lane_int(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __global__ void __launch_bounds__(TB) k_form_K(Ctx c, ResCtx rc) {
   const double sigma = c.prm->sigma;
   if (blockIdx.x == 0 && threadIdx.x == 0) { c.st->res_pipe_off = 0; c.st->res_ver_cnt = 0; }
-  const size_t total = (size_t)rc.nwg * rc.E * RES_PT;
-  for (size_t sl = (size_t)blockIdx.x * TB + threadIdx.x; sl < total; sl += (size_t)gridDim.x * TB) {
-    const int t = (int)(sl % RES_PT), k = (int)((sl / RES_PT) % rc.E), g = (int)(sl / ((size_t)RES_PT * rc.E));
-    const ResWG w = rc.wg[g];
-    double v = 0.0;
-    if (t * rc.E + k < w.cnt) {
-      const int i = w.r0 + rc.rowl[sl], j = rc.col[sl], ps = rc.psrc[sl];
-      v = (ps >= 0 ? c.M.val[ps] : 0.0) + (i == j ? sigma : 0.0);
-      int a = c.M.split[i], b = c.M.split[j];
-      const int ae = c.M.rowptr[i + 1], be = c.M.rowptr[j + 1];
-      while (a < ae && b < be) {
-        const int ka = c.M.col[a], kb = c.M.col[b];
-        if (ka == kb) { v += c.rho[ka - c.n] * (c.M.val[a] * c.M.val[b]); ++a; ++b; }
-        else if (ka < kb) ++a; else ++b;
+  const int lane = threadIdx.x & 63, nwaves = gridDim.x * (TB / 64);
+  for (int i = blockIdx.x * (TB / 64) + (threadIdx.x >> 6); i < c.n; i += nwaves) {
+    const int e0 = rc.krp[i], e1 = rc.krp[i + 1];
+    const int ka = c.M.split[i], kb = c.M.rowptr[i + 1];
+    for (int eb = e0; eb < e1; eb += 256) {
+      int j[4]; double v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = eb + q * 64 + lane;
+        j[q] = -1; v[q] = 0.0;
+        if (idx < e1) {
+          j[q] = rc.kcj[idx];
+          const int ps = rc.kps[idx];
+          v[q] = (ps >= 0 ? c.M.val[ps] : 0.0) + (j[q] == i ? sigma : 0.0);
+        }
+      }
+      for (int kc = ka; kc < kb; kc += 64) {
+        const bool on = kc + lane < kb;
+        const int kk = on ? c.M.col[kc + lane] - c.n : 0;
+        const double ai = on ? c.M.val[kc + lane] : 0.0, rk = on ? c.rho[kk] : 0.0;
+        const int p0 = on ? c.A.rowptr[kk] : 0, p1 = on ? c.A.rowptr[kk + 1] : 0;
+        const int cnt = min(64, kb - kc);
+        for (int q = 0; q < cnt; ++q) {
+          const double a_i = lane_value(ai, q), r = lane_value(rk, q);
+          const int s0 = lane_int(p0, q), s1 = lane_int(p1, q);
+          for (int ec = s0; ec < s1; ec += 64) {
+            const bool eon = ec + lane < s1;
+            const int cj = eon ? c.A.col[ec + lane] : -1;
+            const double av = eon ? c.A.val[ec + lane] : 0.0;
+            const int len = min(64, s1 - ec);
+            for (int e = 0; e < len; ++e) {
+              const int cjb = lane_int(cj, e);
+              const double t = r * (a_i * lane_value(av, e));
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) if (j[q4] == cjb) v[q4] += t;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = eb + q * 64 + lane;
+        if (idx < e1) rc.val[rc.kdst[idx]] = v[q];
       }
     }
-    rc.val[sl] = v;
   }
 }
 
@@ -1106,7 +1139,15 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
           }
         }
         if (__all(ok)) break;
-        if (wall_clock64() - t0 > RES_WAIT_TICKS || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) sc[3] = 1.0; break; }
+        const bool late = wall_clock64() - t0 > RES_WAIT_TICKS;
+        if (late || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          if (late) {             // leave a note for the host's message: who waited for whom
+            const unsigned long long miss = __ballot(!ok);
+            if (lane == 0 && atomicCAS(&st->res_dbg[0], 0, 1) == 0) { st->res_dbg[1] = nx; st->res_dbg[2] = g; st->res_dbg[3] = miss ? (int)__ffsll((long long)miss) - 1 : -1; }
+          }
+          if (lane == 0) sc[3] = 1.0;
+          break;
+        }
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -1177,14 +1218,18 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
       }
     return a;
   };
-  // Exchange (2): three dot partials per workgroup as {value, tag} granules (the data is the flag); totals in sc[0..2].
+  // Exchange (2): three dot partials per workgroup as tagged granules (the data is the flag); totals in sc[0..2].
+  // (A first version kept the double in one half of a 16-byte store and the tag in the other: about one run in ten a sweep
+  // saw the new tag beside the OLD value, the workgroups' sums differed, their stop decisions too, and the launch hung
+  // until its waits timed out.)
   auto scal_exchange = [&](double pg, double pd, double prr) __attribute__((always_inline)) -> bool {
     if (wv == 0) {
       pg = wave_sum(pg); pd = wave_sum(pd); prr = wave_sum(prr);
       const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.sbuf + (size_t)par * nwg * 8, (size_t)nwg * 64);
       if (lane < 3) {
         const double v = lane == 0 ? pg : (lane == 1 ? pd : prr);
-        u32x4 d; d.x = (unsigned)__double2loint(v); d.y = (unsigned)__double2hiint(v); d.z = tag; d.w = tag;
+        // two 8-byte granules {low word, tag}, {high word, tag}: an 8-byte store lands whole, a 16-byte one may land in halves
+        u32x4 d; d.x = (unsigned)__double2loint(v); d.y = tag; d.z = (unsigned)__double2hiint(v); d.w = tag;
         __builtin_amdgcn_raw_buffer_store_b128(d, rs, (g * 4 + lane) * 16, 0, AUX_SC1);
       }
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -1199,18 +1244,26 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
           if (pend & (1u << q)) gr[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((lane + 64 * (q / 3)) * 4 + (q % 3)) * 16, 0, AUX_SC1);
 #pragma unroll
         for (int q = 0; q < 12; ++q)
-          if ((pend & (1u << q)) && gr[q].z == tag && gr[q].w == tag) pend &= ~(1u << q);
+          if ((pend & (1u << q)) && gr[q].y == tag && gr[q].w == tag) pend &= ~(1u << q);
         if (__all(pend == 0)) break;
         asm volatile("" ::: "memory");
-        if (wall_clock64() - t0 > RES_WAIT_TICKS || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) sc[3] = 1.0; break; }
+        const bool late = wall_clock64() - t0 > RES_WAIT_TICKS;
+        if (late || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          if (late) {
+            const unsigned long long miss = __ballot(pend != 0);
+            if (lane == 0 && atomicCAS(&st->res_dbg[0], 0, 2) == 0) { st->res_dbg[1] = nx; st->res_dbg[2] = g; st->res_dbg[3] = miss ? (int)__ffsll((long long)miss) - 1 : -1; }
+          }
+          if (lane == 0) sc[3] = 1.0;
+          break;
+        }
         __builtin_amdgcn_s_sleep(1);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (lane + 64 * q < nwg) {
-          a0 += __hiloint2double((int)gr[3 * q].y, (int)gr[3 * q].x);
-          a1 += __hiloint2double((int)gr[3 * q + 1].y, (int)gr[3 * q + 1].x);
-          a2 += __hiloint2double((int)gr[3 * q + 2].y, (int)gr[3 * q + 2].x);
+          a0 += __hiloint2double((int)gr[3 * q].z, (int)gr[3 * q].x);
+          a1 += __hiloint2double((int)gr[3 * q + 1].z, (int)gr[3 * q + 1].x);
+          a2 += __hiloint2double((int)gr[3 * q + 2].z, (int)gr[3 * q + 2].x);
         }
       a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
       if (lane == 0) { sc[0] = a0; sc[1] = a1; sc[2] = a2; }
@@ -2038,7 +2091,7 @@ static int build_resident(hipeng *e) {
   if (const char *x = getenv("OSQP_AMD_RESIDENT_BANKS")) bank_sched = atoi(x) != 0;
   std::vector<unsigned short> col(slots, 0), slot0((size_t)nwg * RES_PT, 0), segrow((size_t)nwg * (RES_MAXROWS + 1), 0);
   std::vector<unsigned char> rowl(slots, 0);
-  std::vector<int> psrc(slots, -1);
+  std::vector<int> kdst((size_t)nnzK, 0);
   std::vector<unsigned long long> brk((size_t)nwg * RES_PT, 0ull);
   for (int g = 0; g < nwg; g++) {
     const ResWG &w = wg[g];
@@ -2100,7 +2153,7 @@ static int build_resident(hipeng *e) {
         if (t * E + k >= w.cnt) break;
         const int le = ord[t * E + k];
         const size_t sl = ((size_t)g * E + k) * RES_PT + t;
-        col[sl] = (unsigned short)Kcol[base + le]; rowl[sl] = (unsigned char)rowof[le]; psrc[sl] = Kps[base + le];
+        col[sl] = (unsigned short)Kcol[base + le]; rowl[sl] = (unsigned char)rowof[le]; kdst[base + le] = (int)sl;
         while (next_row <= rowof[le]) segrow[(size_t)g * (RES_MAXROWS + 1) + next_row++] = (unsigned short)nseg;   // first segment of the row
         const bool last = k == E - 1 || t * E + k + 1 >= w.cnt || rowof[ord[t * E + k + 1]] != rowof[le];
         if (last) { b |= 1ull << k; nseg++; }
@@ -2117,16 +2170,17 @@ static int build_resident(hipeng *e) {
   rc.u0_direct = 1;
   if (const char *x = getenv("OSQP_AMD_RESIDENT_U0")) rc.u0_direct = atoi(x) != 0;
   ResWG *d_wg = nullptr; unsigned short *d_col = nullptr, *d_slot0 = nullptr, *d_segrow = nullptr; unsigned char *d_rowl = nullptr;
-  int *d_psrc = nullptr; unsigned long long *d_brk = nullptr;
+  int *d_krp = nullptr, *d_kcj = nullptr, *d_kps = nullptr, *d_kdst = nullptr; unsigned long long *d_brk = nullptr;
   if (dev_alloc(e, &d_wg, wg.size()) || dev_alloc(e, &rc.val, slots) || dev_alloc(e, &d_col, slots) || dev_alloc(e, &d_rowl, slots) ||
-      dev_alloc(e, &d_psrc, slots) || dev_alloc(e, &d_brk, brk.size()) || dev_alloc(e, &d_slot0, slot0.size()) ||
+      dev_alloc(e, &d_krp, Kptr.size()) || dev_alloc(e, &d_kcj, Kcol.size()) || dev_alloc(e, &d_kps, Kps.size()) || dev_alloc(e, &d_kdst, kdst.size()) ||
+      dev_alloc(e, &d_brk, brk.size()) || dev_alloc(e, &d_slot0, slot0.size()) ||
       dev_alloc(e, &d_segrow, segrow.size()) || dev_alloc(e, &rc.ubuf, (size_t)2 * (rc.npad + 4 * 256)) ||
       dev_alloc(e, &rc.flags, (size_t)nwg * 16) || dev_alloc(e, &rc.sbuf, (size_t)2 * nwg * 8)) return HIPENG_ERR_HIP;
 #define UP(dst, src) HIPCHK(hipMemcpyAsync(dst, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, e->stream))
-  UP(d_wg, wg); UP(d_col, col); UP(d_rowl, rowl); UP(d_psrc, psrc); UP(d_brk, brk); UP(d_slot0, slot0); UP(d_segrow, segrow);
+  UP(d_wg, wg); UP(d_col, col); UP(d_rowl, rowl); UP(d_krp, Kptr); UP(d_kcj, Kcol); UP(d_kps, Kps); UP(d_kdst, kdst); UP(d_brk, brk); UP(d_slot0, slot0); UP(d_segrow, segrow);
 #undef UP
   HIPCHK(hipStreamSynchronize(e->stream));       // the sources are locals
-  rc.wg = d_wg; rc.col = d_col; rc.rowl = d_rowl; rc.psrc = d_psrc; rc.brk = d_brk; rc.slot0 = d_slot0; rc.segrow = d_segrow;
+  rc.wg = d_wg; rc.col = d_col; rc.rowl = d_rowl; rc.krp = d_krp; rc.kcj = d_kcj; rc.kps = d_kps; rc.kdst = d_kdst; rc.brk = d_brk; rc.slot0 = d_slot0; rc.segrow = d_segrow;
   e->rc = rc;
   e->res_lds = ((size_t)rc.npad + 4 * 256 + RES_TB + RES_MAXROWS + 16 + 5 * 64 + 48) * sizeof(double);   // + phase stamps of the TIMELINE build
   int rcode = 0;
@@ -2151,7 +2205,7 @@ static int elem_grid(int cnt) {
 // Everything derived from (P, A, rho, sigma): the Jacobi preconditioner.
 static void refresh_operator(hipeng *e) {
   hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
-  if (e->res_on) hipLaunchKernelGGL(k_form_K, dim3(1024), dim3(TB), 0, e->stream, e->c, e->rc);
+  if (e->res_on) hipLaunchKernelGGL(k_form_K, dim3(std::min(2048, (e->n + 3) / 4)), dim3(TB), 0, e->stream, e->c, e->rc);
 }
 
 // The PCG start vector history is void (cold/warm start from the host, new rho, new matrices):
@@ -2656,9 +2710,11 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     if (s.res_fail) {
       // the resident launch found its grid not co-resident (the GPU is shared): launch-per-step kernels from here on
       fprintf(stderr, "osqp_amd: resident PCG launch timed out waiting for its workgroups (GPU shared with another stream or process?); "
-                      "continuing with the launch-per-step path\n");
+                      "continuing with the launch-per-step path [wait %d of exchange %d: workgroup %d missed workgroup %d (+64k); PCG iterations so far %d]\n",
+              s.res_dbg[0], s.res_dbg[1], s.res_dbg[2], s.res_dbg[3], std::max(s.iters[0], s.iters[1]));
       e->res_use = false;
       HIPCHK(hipMemsetAsync(&e->c.st->res_fail, 0, sizeof(int), e->stream));
+      HIPCHK(hipMemsetAsync(e->c.st->res_dbg, 0, sizeof(int) * 4, e->stream));
     }
     const long long done_now = s.admm_done - start;
     const bool stalls = count - done_now > remaining - burst;       // some launches were continuations

@@ -2,7 +2,7 @@
 // 256 workgroups (one per CU) each publish `per` doubles per iteration; every workgroup needs all of them in LDS
 // before its next step (the pattern of a CG iteration whose operator rows live in registers).
 //   mode 0: no exchange (loop + barriers + the emulated row work): the floor
-//   mode 1: data-tagged 16-byte granules {double, tag}, sc1 stores, sc1 sweep until every tag matches
+//   mode 1: data-tagged granules {low word, tag, high word, tag} (two 8-byte granules per double), sc1 stores, sc1 sweep until every tag matches
 //   mode 2: sc1 payload (16-byte stores of two doubles), drain, one flag per workgroup, poll flags, sc1 payload loads
 //   mode 4: mode 2 without the drain (payload words self-tagged in their two low mantissa bits, flag stored right behind them)
 //   mode 3: the tag in the two low mantissa bits of every double (8-byte sc1 stores, sc1 sweep until every word carries it)
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(TPB) void k_probe(Args a)
                 int j = g * a.per + t;
                 double v = expected(j, it);
                 u32x4 w;
-                w.x = (unsigned)__double2loint(v); w.y = (unsigned)__double2hiint(v); w.z = tag; w.w = tag;
+                w.x = (unsigned)__double2loint(v); w.y = tag; w.z = (unsigned)__double2hiint(v); w.w = tag;   // two 8-byte granules: a 16-byte store may land in halves
                 __builtin_amdgcn_raw_buffer_store_b128(w, rs, j * 16, 0, AUX_SC1);
             }
             // sweep: thread t takes granules t, t+512, ...
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(TPB) void k_probe(Args a)
                     if (pending & (1u << k)) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (t + k * TPB) * 16, 0, AUX_SC1);
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
-                    if ((pending & (1u << k)) && r[k].z == tag && r[k].w == tag) {
-                        lds[t + k * TPB] = __hiloint2double((int)r[k].y, (int)r[k].x);
+                    if ((pending & (1u << k)) && r[k].y == tag && r[k].w == tag) {
+                        lds[t + k * TPB] = __hiloint2double((int)r[k].z, (int)r[k].x);
                         pending &= ~(1u << k);
                     }
                 if (!pending) break;
@@ -308,12 +308,11 @@ int main(int argc, char **argv)
     CK(hipFuncSetAttribute((const void *)k_probe<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void *)k_probe<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void *)k_probe<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int fstride = 16; fstride <= 128; fstride *= 2)
-    for (int work = 0; work < 1; ++work)
+    const int fstride = argc > 3 ? atoi(argv[3]) : 16;      // flag spacing in 4-byte words (16, 32, 64, 128: no difference measured)
+    for (int work = 0; work < 2; ++work)
         for (int mode = 0; mode < 6; ++mode)
             for (int uneven = 0; uneven < 2; ++uneven) {
                 if (mode == 0 && uneven) continue;
-                if (mode != 2) continue;
                 float best = 1e30f; unsigned herr[2] = {0, 0};
                 for (int rep = 0; rep < 3; ++rep) {
                     CK(hipMemset(buf, 0, (size_t)2 * G * 16));
