@@ -485,6 +485,8 @@ def main():
                        "rho_updates_per_solve": int(last.info.rho_updates) - ru_prev if a.steps > 1 else None,
                        "pcg_iters_per_admm_iter": round(pcg_total / max(1, (a.steps + a.warmup) * last.info.iter), 2),
                        "graph_launches": st["graph_launches"], "host_syncs": st["host_syncs"],
+                       "linear_solves": ("resident launches (K = P + sigma I + A' rho A in registers, one launch per solve)" if st.get("resident")
+                                         else "launch-per-step PCG kernels (k_cg_A, k_cg_B)"),
                        "parallelism": "replicas x%d (a single QP does not shard)" % world},
         }
         if world == 1 and not a.no_inexact:

@@ -95,6 +95,9 @@ typedef struct {
   c_int pcg_forced;
   c_int graph_launches;
   c_int host_syncs;
+  c_int resident;        /* 1: the linear solves run as one resident launch each (K in registers, engine.hip k_pcg_resident);
+                            0: launch-per-step PCG kernels (problem too large for the register files, OSQP_AMD_RESIDENT=0,
+                            or a resident launch found the GPU shared and the engine fell back) */
 } osqp_amd_stats;
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, osqp_amd_stats *st);
 /* The options above are the DEFAULTS a new workspace / plugin instance copies at creation; afterwards

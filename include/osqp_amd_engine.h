@@ -66,6 +66,7 @@ typedef struct {
   c_int graph_launches;
   c_int kernels_per_pcg_iter;
   c_int neg_curvature;   /* solves in which CG met p'Kp <= 0 (K not positive definite) */
+  c_int resident;        /* 1: linear solves as resident launches (k_pcg_resident) */
 } hipeng_stats;
 
 /* Create the device-resident problem.  P (upper triangle) and A are the

@@ -23,7 +23,7 @@ class _Options(C.Structure):
 class _Stats(C.Structure):
     _fields_ = [("pcg_iters_total", abi.c_int), ("pcg_iters_last", abi.c_int),
                 ("pcg_forced", abi.c_int), ("graph_launches", abi.c_int),
-                ("host_syncs", abi.c_int)]
+                ("host_syncs", abi.c_int), ("resident", abi.c_int)]
 
 
 def engine_options():

@@ -2765,6 +2765,7 @@ extern "C" int hipeng_reset_stats(hipeng *e) {
 extern "C" int hipeng_get_stats(hipeng *e, hipeng_stats *st) {
   if (!e || !st) return HIPENG_ERR_ARG;
   *st = e->stats;
+  st->resident = e->res_use ? 1 : 0;
   return 0;
 }
 

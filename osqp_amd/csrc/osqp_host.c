@@ -1223,6 +1223,7 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, osqp_amd_stats *out) {
   out->pcg_iters_total = hs.pcg_iters_total; out->pcg_iters_last = hs.pcg_iters_last;
   out->pcg_forced = hs.pcg_forced; out->graph_launches = hs.graph_launches;
   out->host_syncs = s->host_syncs;
+  out->resident = hs.resident;
   return 0;
 }
 
