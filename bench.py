@@ -86,6 +86,12 @@ def kernel_roofline(solver, reps=300):
         # repetitions of [k_pcg_init, k_pcg_resident] on the engine's stream, minus k_pcg_init timed the same way.
         # Units of one launch: the PCG iterations it ran (read back from the device); bytes per unit: SURVEY 8(d) B_pcg.
         reps2 = 100
+        # a state in the middle of a solve (60 of its 125 iterations): the repeated linear solve is then a typical one
+        # (from the converged iterates the next system needs three PCG iterations)
+        solver.update_rho(RHO0)
+        solver.update_settings(max_iter=60)
+        solver.solve()
+        solver.update_settings(max_iter=4000)
         t_pair = C.c_double(); t_init = C.c_double()
         assert L.hipeng_time_kernel(solver.engine(), 8, reps2, C.byref(t_pair)) == 0
         assert L.hipeng_resident_info(solver.engine(), info) == 0

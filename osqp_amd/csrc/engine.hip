@@ -38,6 +38,7 @@
 #include <map>
 #include <algorithm>
 #include <mutex>
+#include <chrono>
 #include "../../include/osqp_amd_engine.h"
 
 #define TB 256            // threads per workgroup (4 wavefronts of 64)
@@ -950,29 +951,34 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
 // ---------------------------------------------------------------------------
 #define RES_TB 512
 #define RES_PT (RES_TB - 64)   // threads that hold entries of K (wavefronts 1..7); wavefront 0 owns the rows and talks
-#define RES_MAXROWS 64
+#define RES_MAXROWS 61    // rows per workgroup: they and the three riding partials are stored by the 64 lanes of wavefront 0
 #define RES_MAXN (RES_MAXROWS * 256)
-#define RES_MAXLD (RES_MAXN / 2 / RES_TB)   // 16-byte loads per thread that sweep the exchanged vector
+#define RES_MAXPAD 16384  // longest exchanged vector (doubles, lines padded)
+#define RES_MAXLD (RES_MAXPAD / 2 / RES_TB)   // 16-byte loads per thread that sweep the exchanged vector
 #define RES_WAIT_TICKS 2000000LL      // 20 ms of the 100 MHz wall clock per wait
 #define AUX_SC1 16
+#define RES_FSTRIDE 32   // 4-byte words between two workgroups' flags: a 128-byte line each
+#define RES_GSTRIDE 16   // doubles between two workgroups' granule slots: a 128-byte line each (no line is written by two CUs)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-struct ResWG { int r0, nr, cnt, pad; };   // first row, rows (<= RES_MAXROWS), entries of K
+struct ResWG { int r0, nr, cnt, pos; };   // first row, rows (<= RES_MAXROWS), entries of K, first position in the exchanged vector
 struct ResCtx {
-  int nwg, E, npad;                  // workgroups, entries per thread, n rounded up to even
+  int nwg, E, npad;                  // workgroups, entries per thread, length of the exchanged vector: every workgroup's rows + its three
+                                     // dot partials, padded to whole 128-byte lines (a line written by two CUs can lose one of the writes)
+  const unsigned short *rowpos;      // position of row j in that vector
   int pipe;                          // 1: pipelined recurrences where they pass their checks (OSQP_AMD_RESIDENT_PIPE=0: never)
   int u0_direct;                     // 1: the first product reads u0 from global memory instead of exchanging it
   const ResWG *wg;
   double *val;                       // [nwg][E][RES_PT]: entry t*E + k of the workgroup's row-major list at (k, t)
-  const unsigned short *col;         // same layout
+  const unsigned short *col;         // same layout: POSITION of the entry's column in the exchanged vector
   const unsigned char *rowl;         // same layout: local row of the entry
   const int *krp, *kcj, *kps, *kdst; // K row by row for k_form_K: row pointers (n + 1), column, slot in M of P(i,j) (-1: none), slot in val
   const unsigned long long *brk;     // [nwg][RES_PT]: bit k set = entry k ends a row segment of this thread
   const unsigned short *slot0;       // [nwg][RES_PT]: first segment slot of the thread
   const unsigned short *segrow;      // [nwg][RES_MAXROWS + 1]: first segment slot of each local row
-  double *ubuf;                      // 2 x (npad + 4 * 256) doubles (parity of the tag): the vector, then 4 doubles per workgroup
-  unsigned *flags;                   // nwg x 16 words (one 64-byte line each)
-  double *sbuf;                      // 2 x nwg x 4 slots of 16 bytes: {low word, tag, high word, tag} of one double
+  double *ubuf;                      // 2 x npad doubles (parity of the tag)
+  unsigned *flags;                   // nwg x RES_FSTRIDE words (one 128-byte line each)
+  double *sbuf;                      // 2 x nwg x RES_GSTRIDE doubles: three 16-byte slots {low word, tag, high word, tag} per workgroup, one line each
 };
 
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const void *p, size_t bytes) {
@@ -1043,9 +1049,8 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   State *st = c.st;
   TL_MARK(c, 5);
   if (st->stalled || !st->run || st->res_fail) return;
-  double *uv = rlds;                              // npad doubles: the exchanged vector
-  double *tail = uv + rc.npad;                    // 4 doubles per workgroup riding with the vector: dot partials
-  double *seg = tail + 4 * 256;                   // RES_TB + RES_MAXROWS row-segment sums
+  double *uv = rlds;                              // npad doubles: the exchanged vector (rows and riding partials of every workgroup)
+  double *seg = uv + rc.npad;                     // RES_TB + RES_MAXROWS row-segment sums
   double *sc = seg + RES_TB + RES_MAXROWS;        // 4 doubles: gamma, delta, rr, fail word
 #ifdef OSQP_AMD_TIMELINE
   long long *tls = reinterpret_cast<long long *>(sc + 8);   // phase stamps of the first 64 exchanges (workgroup 0)
@@ -1083,6 +1088,9 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
     slot0 = rc.slot0[(size_t)g * RES_PT + tt];
   }
   int sr0 = 0, sr1 = 0;
+  int ppos[4];                         // where the partials of workgroups lane, lane + 64, ... sit in the exchanged vector
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int o = lane + 64 * q; ppos[q] = 0; if (o < rc.nwg) { const ResWG wo = rc.wg[o]; ppos[q] = wo.pos + wo.nr; } }
   // ---- start-up scalars: ||r0||^2, ||b||^2 from k_pcg_init's partials (every wavefront, same order) ----
   double rr0 = 0.0, bb = 0.0;
   for (int i = lane; i < c.gridM; i += 64) { rr0 += c.part_rr[i]; bb += c.part_bb[i]; }
@@ -1113,20 +1121,16 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   auto vec_exchange = [&](double val, double e0, double e1, double e2) __attribute__((always_inline)) -> bool {
     ++nx; tag = ep0 + (unsigned)nx; par = (int)(tag & 1u);
     RTL(0);
-    const size_t stride = (size_t)npad + 4 * 256;
-    const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.ubuf + (size_t)par * stride, stride * 8);
+    const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.ubuf + (size_t)par * npad, (size_t)npad * 8);
     if (wv == 0) {
-      if (own) {
-        u32x2 d; d.x = (unsigned)__double2loint(val); d.y = (unsigned)__double2hiint(val);
-        __builtin_amdgcn_raw_buffer_store_b64(d, rs, j * 8, 0, AUX_SC1);
-      }
-      if (lane < 3) {
-        const double v = lane == 0 ? e0 : (lane == 1 ? e1 : e2);
+      // rows at pos .. pos + nr - 1, the three riding partials right behind them: all inside this workgroup's own lines
+      if (lane < w.nr + 3) {
+        const double v = lane < w.nr ? val : (lane == w.nr ? e0 : (lane == w.nr + 1 ? e1 : e2));
         u32x2 d; d.x = (unsigned)__double2loint(v); d.y = (unsigned)__double2hiint(v);
-        __builtin_amdgcn_raw_buffer_store_b64(d, rs, (npad + 4 * g + lane) * 8, 0, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rs, (w.pos + lane) * 8, 0, AUX_SC1);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(rc.flags + (size_t)g * 16, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(rc.flags + (size_t)g * RES_FSTRIDE, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const long long t0 = wall_clock64();
       while (true) {
         bool ok = true;
@@ -1134,7 +1138,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
         for (int q = 0; q < 4; ++q) {
           const int o = lane + 64 * q;
           if (o < nwg) {
-            const unsigned f = __hip_atomic_load(rc.flags + (size_t)o * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned f = __hip_atomic_load(rc.flags + (size_t)o * RES_FSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok &= (int)(f - tag) >= 0;
           }
         }
@@ -1158,16 +1162,13 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
     {
       const int half = npad >> 1;
       u32x4 v[RES_MAXLD];              // every load of the sweep in flight at once
-      u32x4 vt;
 #pragma unroll
       for (int q = 0; q < RES_MAXLD; ++q) { const int i2 = q * RES_TB + t; if (i2 < half) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, i2 * 16, 0, AUX_SC1); }
-      if (t < 2 * nwg) vt = __builtin_amdgcn_raw_buffer_load_b128(rs, (half + t) * 16, 0, AUX_SC1);
 #pragma unroll
       for (int q = 0; q < RES_MAXLD; ++q) {
         const int i2 = q * RES_TB + t;
         if (i2 < half) { uv[2 * i2] = __hiloint2double((int)v[q].y, (int)v[q].x); uv[2 * i2 + 1] = __hiloint2double((int)v[q].w, (int)v[q].z); }
       }
-      if (t < 2 * nwg) { tail[2 * t] = __hiloint2double((int)vt.y, (int)vt.x); tail[2 * t + 1] = __hiloint2double((int)vt.w, (int)vt.z); }
     }
     __syncthreads();
     RTL(2);
@@ -1177,11 +1178,8 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   // in the lanes of wavefront 0 (ends with the barrier that makes the segments visible)
   // u0 = Minv r0 was left in global memory by k_pcg_init (an earlier launch: plain loads see it): no exchange needed
   auto load_u0 = [&]() __attribute__((always_inline)) {
-    const double2 *src = reinterpret_cast<const double2 *>(c.init_z);
-    const int half = c.n >> 1;
 #pragma unroll 4
-    for (int i2 = t; i2 < half; i2 += RES_TB) { const double2 v = src[i2]; uv[2 * i2] = v.x; uv[2 * i2 + 1] = v.y; }
-    if ((c.n & 1) && t == 0) uv[c.n - 1] = c.init_z[c.n - 1];
+    for (int jj = t; jj < c.n; jj += RES_TB) uv[rc.rowpos[jj]] = c.init_z[jj];
     __syncthreads();
   };
   auto products_issue = [&]() __attribute__((always_inline)) {
@@ -1225,12 +1223,12 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   auto scal_exchange = [&](double pg, double pd, double prr) __attribute__((always_inline)) -> bool {
     if (wv == 0) {
       pg = wave_sum(pg); pd = wave_sum(pd); prr = wave_sum(prr);
-      const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.sbuf + (size_t)par * nwg * 8, (size_t)nwg * 64);
+      const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.sbuf + (size_t)par * nwg * RES_GSTRIDE, (size_t)nwg * RES_GSTRIDE * 8);
       if (lane < 3) {
         const double v = lane == 0 ? pg : (lane == 1 ? pd : prr);
         // two 8-byte granules {low word, tag}, {high word, tag}: an 8-byte store lands whole, a 16-byte one may land in halves
         u32x4 d; d.x = (unsigned)__double2loint(v); d.y = tag; d.z = (unsigned)__double2hiint(v); d.w = tag;
-        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (g * 4 + lane) * 16, 0, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, g * (RES_GSTRIDE * 8) + lane * 16, 0, AUX_SC1);
       }
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;
       unsigned pend = 0;
@@ -1241,7 +1239,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
       while (true) {
 #pragma unroll
         for (int q = 0; q < 12; ++q)
-          if (pend & (1u << q)) gr[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((lane + 64 * (q / 3)) * 4 + (q % 3)) * 16, 0, AUX_SC1);
+          if (pend & (1u << q)) gr[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * (q / 3)) * (RES_GSTRIDE * 8) + (q % 3) * 16, 0, AUX_SC1);
 #pragma unroll
         for (int q = 0; q < 12; ++q)
           if ((pend & (1u << q)) && gr[q].y == tag && gr[q].w == tag) pend &= ~(1u << q);
@@ -1302,7 +1300,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
     if (mode == 1 && wv == 0) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) if (lane + 64 * q < nwg) { a0 += tail[4 * (lane + 64 * q)]; a1 += tail[4 * (lane + 64 * q) + 1]; a2 += tail[4 * (lane + 64 * q) + 2]; }
+      for (int q = 0; q < 4; ++q) if (lane + 64 * q < nwg) { a0 += uv[ppos[q]]; a1 += uv[ppos[q] + 1]; a2 += uv[ppos[q] + 2]; }
       const double gam = wave_sum(a0), del = wave_sum(a1), rr = wave_sum(a2);
       cs = cg_step(rr, gam, del, gam_old, alp_old, tol2, iters, 0, prm, false);
       gam_old = gam; alp_old = cs.alpha;
@@ -2030,6 +2028,7 @@ static int build_resident(hipeng *e) {
   const int nwg = std::min(256, prop.multiProcessorCount);
   if ((long long)nwg * RES_MAXROWS < n || prop.sharedMemPerBlock < 64 * 1024) RES_NO("too few CUs or too little LDS");
   const HostMat &M = e->M, &A = e->A;
+  const auto tb0 = std::chrono::steady_clock::now();
   for (int i = 0; i < n; i++)
     for (int k = M.split[i] + 1; k < M.rowptr[i + 1]; k++) if (M.col[k] <= M.col[k - 1]) RES_NO("a column of A is not sorted by row (or repeats one)");   // the merge in k_form_K wants ascending rows
   // pattern of K, row by row (sorted), with the slot of P(i,j) in M
@@ -2057,6 +2056,7 @@ static int build_resident(hipeng *e) {
     Kptr[i + 1] = (int)Kcol.size();
   }
   const long long nnzK = Kptr[n];
+  const auto tb1 = std::chrono::steady_clock::now();
   // contiguous row blocks, at most RES_MAXROWS rows and C entries each: smallest C that needs <= nwg blocks
   auto packs = [&](long long C) -> int {
     int g = 0, rows = 0; long long cnt = 0;
@@ -2086,6 +2086,15 @@ static int build_resident(hipeng *e) {
     }
     wg[g].nr = rows; wg[g].cnt = (int)cnt;
   }
+  // positions in the exchanged vector: a workgroup's rows, then its three dot partials, in lines of its own
+  std::vector<unsigned short> rowpos(n, 0);
+  int npad = 0;
+  for (int g = 0; g < nwg; g++) {
+    wg[g].pos = npad;
+    for (int r = 0; r < wg[g].nr; r++) rowpos[wg[g].r0 + r] = (unsigned short)(npad + r);
+    npad += ((wg[g].nr + 3 + 15) / 16) * 16;
+  }
+  if (npad > RES_MAXPAD) RES_NO("the exchanged vector (rows padded to whole lines) exceeds 16384 doubles");
   const size_t slots = (size_t)nwg * E * RES_PT;
   bool bank_sched = true;
   if (const char *x = getenv("OSQP_AMD_RESIDENT_BANKS")) bank_sched = atoi(x) != 0;
@@ -2103,7 +2112,8 @@ static int build_resident(hipeng *e) {
     // Order of the entries inside each thread's chunk.  One wave instruction of the product loop gathers 64 doubles from
     // LDS at the columns of the lanes' k-th entries; random columns pile up to ~6 lanes on one of the 32 bank pairs.
     // A chunk that lies inside one row may be summed in any order, so its entries are dealt to the E slots such that
-    // each slot spreads over the bank pairs (greedy deal + pairwise swaps; deterministic).
+    // each slot spreads over the bank pairs (a greedy deal, deterministic; pairwise swaps on top of it cost 0.3 s of setup
+    // at config 2 for nothing measurable).
     std::vector<int> ord((size_t)RES_PT * E, -1);
     for (int le = 0; le < w.cnt; le++) ord[le] = le;
     if (bank_sched)
@@ -2114,35 +2124,16 @@ static int build_resident(hipeng *e) {
       for (int l = 0; l < 64; l++) {
         const int t = wq * 64 + l, a = t * E;
         freec[l] = a + E <= w.cnt && rowof[a] == rowof[a + E - 1];
-        if (!freec[l]) for (int k = 0; k < E && a + k < w.cnt; k++) cntb[k][Kcol[base + a + k] & 31]++;
+        if (!freec[l]) for (int k = 0; k < E && a + k < w.cnt; k++) cntb[k][rowpos[Kcol[base + a + k]] & 31]++;
       }
       for (int k = 0; k < E; k++)                 // deal: slot by slot, every free lane gives the entry whose bank pair is emptiest
         for (int l = 0; l < 64; l++) {
           if (!freec[l]) continue;
           const int a = (wq * 64 + l) * E;
           int best = k, bc = 1 << 30;
-          for (int q = k; q < E; q++) { const int c = cntb[k][Kcol[base + ord[a + q]] & 31]; if (c < bc) { bc = c; best = q; } }
+          for (int q = k; q < E; q++) { const int c = cntb[k][rowpos[Kcol[base + ord[a + q]]] & 31]; if (c < bc) { bc = c; best = q; } }
           std::swap(ord[a + k], ord[a + best]);
-          cntb[k][Kcol[base + ord[a + k]] & 31]++;
-        }
-      auto slot_max = [&](int k) { int mx = 0; for (int b = 0; b < 32; b++) mx = std::max(mx, cntb[k][b]); return mx; };
-      for (int pass = 0; pass < 4; pass++)        // swaps between two slots of one lane that lower the two slots' maxima
-        for (int l = 0; l < 64; l++) {
-          if (!freec[l]) continue;
-          const int a = (wq * 64 + l) * E;
-          for (int k = 0; k < E; k++) {
-            const int bk = Kcol[base + ord[a + k]] & 31;
-            if (cntb[k][bk] < slot_max(k) || cntb[k][bk] <= 2) continue;
-            for (int q = 0; q < E; q++) {
-              if (q == k) continue;
-              const int bq = Kcol[base + ord[a + q]] & 31;
-              if (bq == bk) continue;
-              const int before = slot_max(k) + slot_max(q);
-              cntb[k][bk]--; cntb[k][bq]++; cntb[q][bq]--; cntb[q][bk]++;
-              if (slot_max(k) + slot_max(q) < before) { std::swap(ord[a + k], ord[a + q]); break; }
-              cntb[k][bk]++; cntb[k][bq]--; cntb[q][bq]++; cntb[q][bk]--;
-            }
-          }
+          cntb[k][rowpos[Kcol[base + ord[a + k]]] & 31]++;
         }
     }
     int nseg = 0, next_row = 0;
@@ -2153,7 +2144,7 @@ static int build_resident(hipeng *e) {
         if (t * E + k >= w.cnt) break;
         const int le = ord[t * E + k];
         const size_t sl = ((size_t)g * E + k) * RES_PT + t;
-        col[sl] = (unsigned short)Kcol[base + le]; rowl[sl] = (unsigned char)rowof[le]; kdst[base + le] = (int)sl;
+        col[sl] = rowpos[Kcol[base + le]]; rowl[sl] = (unsigned char)rowof[le]; kdst[base + le] = (int)sl;
         while (next_row <= rowof[le]) segrow[(size_t)g * (RES_MAXROWS + 1) + next_row++] = (unsigned short)nseg;   // first segment of the row
         const bool last = k == E - 1 || t * E + k + 1 >= w.cnt || rowof[ord[t * E + k + 1]] != rowof[le];
         if (last) { b |= 1ull << k; nseg++; }
@@ -2163,26 +2154,28 @@ static int build_resident(hipeng *e) {
     for (int r = next_row; r <= RES_MAXROWS; r++) segrow[(size_t)g * (RES_MAXROWS + 1) + r] = (unsigned short)nseg;
     if (nseg > RES_TB + RES_MAXROWS) return 0;   // cannot happen (one segment per thread plus one per row change)
   }
+  const auto tb2 = std::chrono::steady_clock::now();
   ResCtx rc{};
-  rc.nwg = nwg; rc.E = E; rc.npad = (n + 1) & ~1;
+  rc.nwg = nwg; rc.E = E; rc.npad = npad;
   rc.pipe = 1;
   if (const char *x = getenv("OSQP_AMD_RESIDENT_PIPE")) rc.pipe = atoi(x) != 0;
   rc.u0_direct = 1;
   if (const char *x = getenv("OSQP_AMD_RESIDENT_U0")) rc.u0_direct = atoi(x) != 0;
+  unsigned short *d_rowpos = nullptr;
   ResWG *d_wg = nullptr; unsigned short *d_col = nullptr, *d_slot0 = nullptr, *d_segrow = nullptr; unsigned char *d_rowl = nullptr;
   int *d_krp = nullptr, *d_kcj = nullptr, *d_kps = nullptr, *d_kdst = nullptr; unsigned long long *d_brk = nullptr;
   if (dev_alloc(e, &d_wg, wg.size()) || dev_alloc(e, &rc.val, slots) || dev_alloc(e, &d_col, slots) || dev_alloc(e, &d_rowl, slots) ||
       dev_alloc(e, &d_krp, Kptr.size()) || dev_alloc(e, &d_kcj, Kcol.size()) || dev_alloc(e, &d_kps, Kps.size()) || dev_alloc(e, &d_kdst, kdst.size()) ||
       dev_alloc(e, &d_brk, brk.size()) || dev_alloc(e, &d_slot0, slot0.size()) ||
-      dev_alloc(e, &d_segrow, segrow.size()) || dev_alloc(e, &rc.ubuf, (size_t)2 * (rc.npad + 4 * 256)) ||
-      dev_alloc(e, &rc.flags, (size_t)nwg * 16) || dev_alloc(e, &rc.sbuf, (size_t)2 * nwg * 8)) return HIPENG_ERR_HIP;
+      dev_alloc(e, &d_segrow, segrow.size()) || dev_alloc(e, &d_rowpos, rowpos.size()) || dev_alloc(e, &rc.ubuf, (size_t)2 * rc.npad) ||
+      dev_alloc(e, &rc.flags, (size_t)nwg * RES_FSTRIDE) || dev_alloc(e, &rc.sbuf, (size_t)2 * nwg * RES_GSTRIDE)) return HIPENG_ERR_HIP;
 #define UP(dst, src) HIPCHK(hipMemcpyAsync(dst, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, e->stream))
-  UP(d_wg, wg); UP(d_col, col); UP(d_rowl, rowl); UP(d_krp, Kptr); UP(d_kcj, Kcol); UP(d_kps, Kps); UP(d_kdst, kdst); UP(d_brk, brk); UP(d_slot0, slot0); UP(d_segrow, segrow);
+  UP(d_wg, wg); UP(d_rowpos, rowpos); UP(d_col, col); UP(d_rowl, rowl); UP(d_krp, Kptr); UP(d_kcj, Kcol); UP(d_kps, Kps); UP(d_kdst, kdst); UP(d_brk, brk); UP(d_slot0, slot0); UP(d_segrow, segrow);
 #undef UP
   HIPCHK(hipStreamSynchronize(e->stream));       // the sources are locals
-  rc.wg = d_wg; rc.col = d_col; rc.rowl = d_rowl; rc.krp = d_krp; rc.kcj = d_kcj; rc.kps = d_kps; rc.kdst = d_kdst; rc.brk = d_brk; rc.slot0 = d_slot0; rc.segrow = d_segrow;
+  rc.wg = d_wg; rc.rowpos = d_rowpos; rc.col = d_col; rc.rowl = d_rowl; rc.krp = d_krp; rc.kcj = d_kcj; rc.kps = d_kps; rc.kdst = d_kdst; rc.brk = d_brk; rc.slot0 = d_slot0; rc.segrow = d_segrow;
   e->rc = rc;
-  e->res_lds = ((size_t)rc.npad + 4 * 256 + RES_TB + RES_MAXROWS + 16 + 5 * 64 + 48) * sizeof(double);   // + phase stamps of the TIMELINE build
+  e->res_lds = ((size_t)rc.npad + RES_TB + RES_MAXROWS + 3 + 16 + 5 * 64 + 48) * sizeof(double);   // + phase stamps of the TIMELINE build
   int rcode = 0;
   switch (E) {
     case 8: rcode = res_set_lds<8>(e->res_lds); break;   case 16: rcode = res_set_lds<16>(e->res_lds); break;
@@ -2193,7 +2186,12 @@ static int build_resident(hipeng *e) {
   if (rcode) return rcode;
   e->res_nnz = nnzK;
   e->res_on = e->res_use = true;
-  if (e->trace) fprintf(stderr, "[osqp_amd] resident PCG: nnz(K)=%lld, %d workgroups x %d threads x %d entries, %zu B LDS\n", nnzK, nwg, RES_TB, E, e->res_lds);
+  if (e->trace) {
+    const auto tb3 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[osqp_amd] resident PCG: nnz(K)=%lld, %d workgroups x %d threads x %d entries, %zu B LDS; host: pattern %.0f ms, layout %.0f ms, upload %.0f ms\n",
+            nnzK, nwg, RES_TB, E, e->res_lds, ms(tb0, tb1), ms(tb1, tb2), ms(tb2, tb3));
+  }
   return 0;
 }
 
@@ -2974,26 +2972,22 @@ extern "C" int hipeng_resident_info(hipeng *e, long long out[8]) {
 }
 
 // Resident PCG, for the tests: the rows of K as the resident kernel holds them.  row/col/val receive nnz(K) triplets
-// (row-major inside each workgroup's block, in the order the threads hold them); returns the count or a negative code.
+// (row by row, columns ascending; values read from the slots the threads load them from); returns the count or a negative code.
 extern "C" long long hipeng_resident_dump(hipeng *e, int *row, int *col, double *val, long long cap) {
   if (!e || !e->res_on || !row || !col || !val) return HIPENG_ERR_ARG;
   if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) return HIPENG_ERR_HIP;
   const ResCtx &rc = e->rc;
   const size_t slots = (size_t)rc.nwg * rc.E * RES_PT;
-  std::vector<double> v(slots); std::vector<unsigned short> cc(slots); std::vector<unsigned char> rl(slots); std::vector<ResWG> wg(rc.nwg);
+  const long long nnz = e->res_nnz;
+  if (nnz > cap) return HIPENG_ERR_ARG;
+  std::vector<double> v(slots); std::vector<int> krp(e->n + 1), kcj((size_t)nnz), kdst((size_t)nnz);
   if (hipMemcpy(v.data(), rc.val, slots * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(cc.data(), rc.col, slots * sizeof(unsigned short), hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(rl.data(), rc.rowl, slots, hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(wg.data(), rc.wg, wg.size() * sizeof(ResWG), hipMemcpyDeviceToHost) != hipSuccess) return HIPENG_ERR_HIP;
+      hipMemcpy(krp.data(), rc.krp, krp.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(kcj.data(), rc.kcj, kcj.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(kdst.data(), rc.kdst, kdst.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return HIPENG_ERR_HIP;
   long long k = 0;
-  for (int g = 0; g < rc.nwg; g++)
-    for (int t = 0; t < RES_PT; t++)
-      for (int q = 0; q < rc.E; q++) {
-        if (t * rc.E + q >= wg[g].cnt) break;
-        const size_t sl = ((size_t)g * rc.E + q) * RES_PT + t;
-        if (k >= cap) return HIPENG_ERR_ARG;
-        row[k] = wg[g].r0 + rl[sl]; col[k] = cc[sl]; val[k] = v[sl]; k++;
-      }
+  for (int i = 0; i < e->n; i++)
+    for (int q = krp[i]; q < krp[i + 1]; q++) { row[k] = i; col[k] = kcj[q]; val[k] = v[kdst[q]]; k++; }
   return k;
 }
 
