@@ -2183,7 +2183,7 @@ static int build_resident(hipeng *e) {
     case 32: rcode = res_set_lds<32>(e->res_lds); break; case 48: rcode = res_set_lds<48>(e->res_lds); break;
     default: rcode = res_set_lds<64>(e->res_lds); break;
   }
-  if (rcode) return rcode;
+  if (rcode) RES_NO("the launch's LDS request was refused");
   e->res_nnz = nnzK;
   e->res_on = e->res_use = true;
   if (e->trace) {
