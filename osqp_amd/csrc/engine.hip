@@ -978,7 +978,8 @@ struct ResCtx {
   const unsigned short *segrow;      // [nwg][RES_MAXROWS + 1]: first segment slot of each local row
   double *ubuf;                      // 2 x npad doubles (parity of the tag)
   unsigned *flags;                   // nwg x RES_FSTRIDE words (one 128-byte line each)
-  double *sbuf;                      // 2 x nwg x RES_GSTRIDE doubles: three 16-byte slots {low word, tag, high word, tag} per workgroup, one line each
+  int *dbg;                          // nwg x 4: exchange number, mode, PCG iterations, 1 + kind of the wait that timed out (0: left because another did)
+  double *sbuf;                      // 2 x nwg x RES_GSTRIDE 8-byte words: six granules {32 bits of a double, tag} per workgroup, one line each
 };
 
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const void *p, size_t bytes) {
@@ -1132,6 +1133,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(rc.flags + (size_t)g * RES_FSTRIDE, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const long long t0 = wall_clock64();
+      unsigned rounds = 0;
       while (true) {
         bool ok = true;
 #pragma unroll
@@ -1152,6 +1154,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
           if (lane == 0) sc[3] = 1.0;
           break;
         }
+        if ((++rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -1217,34 +1220,31 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
     return a;
   };
   // Exchange (2): three dot partials per workgroup as tagged granules (the data is the flag); totals in sc[0..2].
-  // (A first version kept the double in one half of a 16-byte store and the tag in the other: about one run in ten a sweep
-  // saw the new tag beside the OLD value, the workgroups' sums differed, their stop decisions too, and the launch hung
-  // until its waits timed out.)
   auto scal_exchange = [&](double pg, double pd, double prr) __attribute__((always_inline)) -> bool {
     if (wv == 0) {
       pg = wave_sum(pg); pd = wave_sum(pd); prr = wave_sum(prr);
-      const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.sbuf + (size_t)par * nwg * RES_GSTRIDE, (size_t)nwg * RES_GSTRIDE * 8);
-      if (lane < 3) {
-        const double v = lane == 0 ? pg : (lane == 1 ? pd : prr);
-        // two 8-byte granules {low word, tag}, {high word, tag}: an 8-byte store lands whole, a 16-byte one may land in halves
-        u32x4 d; d.x = (unsigned)__double2loint(v); d.y = tag; d.z = (unsigned)__double2hiint(v); d.w = tag;
-        __builtin_amdgcn_raw_buffer_store_b128(d, rs, g * (RES_GSTRIDE * 8) + lane * 16, 0, AUX_SC1);
+      // granules of 8 bytes {32 bits of data, tag}, stored and polled with agent-scope atomic accesses
+      // (global_store/load_dwordx2 sc1): six per workgroup, in a line of the workgroup's own
+      unsigned long long *gb = reinterpret_cast<unsigned long long *>(rc.sbuf) + (size_t)par * nwg * RES_GSTRIDE;
+      if (lane < 6) {
+        const double v = lane < 2 ? pg : (lane < 4 ? pd : prr);
+        const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+        __hip_atomic_store(gb + (size_t)g * RES_GSTRIDE + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-      unsigned pend = 0;
+      unsigned pend = 0;                     // bit 6 q + c: granule c of workgroup lane + 64 q still missing
 #pragma unroll
-      for (int q = 0; q < 4; ++q) if (lane + 64 * q < nwg) pend |= 7u << (3 * q);
-      u32x4 gr[12];
+      for (int q = 0; q < 4; ++q) if (lane + 64 * q < nwg) pend |= 63u << (6 * q);
+      unsigned gv[24];
       const long long t0 = wall_clock64();
+      unsigned rounds = 0;
       while (true) {
 #pragma unroll
-        for (int q = 0; q < 12; ++q)
-          if (pend & (1u << q)) gr[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * (q / 3)) * (RES_GSTRIDE * 8) + (q % 3) * 16, 0, AUX_SC1);
-#pragma unroll
-        for (int q = 0; q < 12; ++q)
-          if ((pend & (1u << q)) && gr[q].y == tag && gr[q].w == tag) pend &= ~(1u << q);
+        for (int q = 0; q < 24; ++q)
+          if (pend & (1u << q)) {
+            const unsigned long long x = __hip_atomic_load(gb + (size_t)(lane + 64 * (q / 6)) * RES_GSTRIDE + (q % 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(x >> 32) == tag) { gv[q] = (unsigned)x; pend &= ~(1u << q); }
+          }
         if (__all(pend == 0)) break;
-        asm volatile("" ::: "memory");
         const bool late = wall_clock64() - t0 > RES_WAIT_TICKS;
         if (late || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           if (late) {
@@ -1254,14 +1254,16 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
           if (lane == 0) sc[3] = 1.0;
           break;
         }
+        if ((++rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // a poll that stays unanswered this long: drop whatever this CU still caches
         __builtin_amdgcn_s_sleep(1);
       }
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (lane + 64 * q < nwg) {
-          a0 += __hiloint2double((int)gr[3 * q].z, (int)gr[3 * q].x);
-          a1 += __hiloint2double((int)gr[3 * q + 1].z, (int)gr[3 * q + 1].x);
-          a2 += __hiloint2double((int)gr[3 * q + 2].z, (int)gr[3 * q + 2].x);
+          a0 += __hiloint2double((int)gv[6 * q + 1], (int)gv[6 * q]);
+          a1 += __hiloint2double((int)gv[6 * q + 3], (int)gv[6 * q + 2]);
+          a2 += __hiloint2double((int)gv[6 * q + 5], (int)gv[6 * q + 4]);
         }
       a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
       if (lane == 0) { sc[0] = a0; sc[1] = a1; sc[2] = a2; }
@@ -1356,7 +1358,10 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
     }
   }
   if (failed) {
-    if (t == 0) __hip_atomic_store(&st->res_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) {
+      __hip_atomic_store(&st->res_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      rc.dbg[4 * g] = nx; rc.dbg[4 * g + 1] = mode; rc.dbg[4 * g + 2] = iters; rc.dbg[4 * g + 3] = 1;
+    }
     return;
   }
   if (own && iters > 0) c.va[j] = x_;
@@ -2168,7 +2173,7 @@ static int build_resident(hipeng *e) {
       dev_alloc(e, &d_krp, Kptr.size()) || dev_alloc(e, &d_kcj, Kcol.size()) || dev_alloc(e, &d_kps, Kps.size()) || dev_alloc(e, &d_kdst, kdst.size()) ||
       dev_alloc(e, &d_brk, brk.size()) || dev_alloc(e, &d_slot0, slot0.size()) ||
       dev_alloc(e, &d_segrow, segrow.size()) || dev_alloc(e, &d_rowpos, rowpos.size()) || dev_alloc(e, &rc.ubuf, (size_t)2 * rc.npad) ||
-      dev_alloc(e, &rc.flags, (size_t)nwg * RES_FSTRIDE) || dev_alloc(e, &rc.sbuf, (size_t)2 * nwg * RES_GSTRIDE)) return HIPENG_ERR_HIP;
+      dev_alloc(e, &rc.flags, (size_t)nwg * RES_FSTRIDE) || dev_alloc(e, &rc.dbg, (size_t)nwg * 4) || dev_alloc(e, &rc.sbuf, (size_t)2 * nwg * RES_GSTRIDE)) return HIPENG_ERR_HIP;
 #define UP(dst, src) HIPCHK(hipMemcpyAsync(dst, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, e->stream))
   UP(d_wg, wg); UP(d_rowpos, rowpos); UP(d_col, col); UP(d_rowl, rowl); UP(d_krp, Kptr); UP(d_kcj, Kcol); UP(d_kps, Kps); UP(d_kdst, kdst); UP(d_brk, brk); UP(d_slot0, slot0); UP(d_segrow, segrow);
 #undef UP
@@ -2710,6 +2715,24 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
       fprintf(stderr, "osqp_amd: resident PCG launch timed out waiting for its workgroups (GPU shared with another stream or process?); "
                       "continuing with the launch-per-step path [wait %d of exchange %d: workgroup %d missed workgroup %d (+64k); PCG iterations so far %d]\n",
               s.res_dbg[0], s.res_dbg[1], s.res_dbg[2], s.res_dbg[3], std::max(s.iters[0], s.iters[1]));
+      {   // where every workgroup stood when it gave up
+        std::vector<int> d((size_t)e->rc.nwg * 4), fl((size_t)e->rc.nwg * RES_FSTRIDE);
+        if (hipMemcpy(d.data(), e->rc.dbg, d.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(fl.data(), e->rc.flags, fl.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
+          std::map<long long, int> hist;
+          for (int g = 0; g < e->rc.nwg; g++) hist[((long long)d[4 * g] << 16) | (d[4 * g + 1] << 8) | (d[4 * g + 3] & 255)]++;
+          fprintf(stderr, "osqp_amd:   workgroups by (exchange, mode, reported):");
+          for (auto &h : hist) fprintf(stderr, " (%lld, %lld, %lld) x %d;", h.first >> 16, (h.first >> 8) & 255, h.first & 255, h.second);
+          fprintf(stderr, "\nosqp_amd:   odd ones:");
+          const long long common = std::max_element(hist.begin(), hist.end(), [](const std::pair<const long long, int> &a, const std::pair<const long long, int> &b) { return a.second < b.second; })->first;
+          int shown = 0;
+          for (int g = 0; g < e->rc.nwg && shown < 8; g++) {
+            const long long key = ((long long)d[4 * g] << 16) | (d[4 * g + 1] << 8) | (d[4 * g + 3] & 255);
+            if (key != common) { fprintf(stderr, " wg %d: exchange %d mode %d iters %d flag %u;", g, d[4 * g], d[4 * g + 1], d[4 * g + 2], (unsigned)fl[(size_t)g * RES_FSTRIDE]); shown++; }
+          }
+          fprintf(stderr, " (epoch base %u)\n", s.res_epoch);
+        }
+      }
       e->res_use = false;
       HIPCHK(hipMemsetAsync(&e->c.st->res_fail, 0, sizeof(int), e->stream));
       HIPCHK(hipMemsetAsync(e->c.st->res_dbg, 0, sizeof(int) * 4, e->stream));

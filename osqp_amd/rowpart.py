@@ -209,7 +209,7 @@ class RowPartitionedOSQP:
         `ops_factory(Pu_g, A_g, device)` builds the rank's SpMV back end (HipOps on a GPU)."""
         st = dict(rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000, check_termination=25,
                   adaptive_rho=1, adaptive_rho_interval=0, adaptive_rho_tolerance=5.0, scaled_termination=0,
-                  pcg_eps_rel=1e-10, pcg_max_iter=0)
+                  pcg_eps_rel=1e-9, pcg_max_iter=0)
         for k, v in settings.items():
             if k not in st:
                 raise ValueError("unsupported setting %r in the row-partitioned variant" % k)
@@ -329,9 +329,9 @@ class RowPartitionedOSQP:
         from types import SimpleNamespace
         st, o, t = self.st, self.ops, self.torch
         e = min(st["eps_abs"] or st["eps_rel"], st["eps_rel"] or st["eps_abs"])
-        eps_pcg = max(1e-13, min(st["pcg_eps_rel"], 1e-6 * e))
+        eps_pcg = max(1e-13, min(st["pcg_eps_rel"], 1e-5 * e))      # the rule of osqp_solve (osqp_host.c)
         if self.has_eq:
-            eps_pcg = max(1e-13, 1e-2 * eps_pcg)
+            eps_pcg = max(1e-13, 1e-3 * eps_pcg)
         interval = st["adaptive_rho_interval"] or (4 * st["check_termination"] if st["check_termination"] else 100)
         self.pcg_iters = 0
         alpha, sigma = st["alpha"], st["sigma"]

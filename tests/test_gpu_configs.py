@@ -25,13 +25,14 @@ def _kkt(pb, r):
 
 
 # These two families are equality-heavy (rho_eq = 1e3 rho): a PCG stop relative to ||b|| at the plain
-# default (1e-10) left x, y 1e-5 relative from the direct solve.  osqp_solve therefore tightens the stop by
-# 1e-2 whenever the problem has equality rows (osqp_host.c), and the usual bars hold at the DEFAULT options:
+# stop of 1e-10 left x, y 1e-5 relative from the direct solve.  osqp_solve therefore tightens the stop by
+# 1e-3 whenever the problem has equality rows (osqp_host.c: 1e-5 eps, 1e-8 eps with equality rows), and the usual bars
+# hold at the DEFAULT options:
 # x, y <= 1e-6 relative, objective <= 1e-8.
 @pytest.fixture
 def pcg_tol():
     import osqp_amd
-    assert osqp_amd.engine_options()["pcg_eps_rel"] == 1e-10      # the tests run on the defaults
+    assert osqp_amd.engine_options()["pcg_eps_rel"] == 1e-9      # the tests run on the defaults
     return 1e-6, 1e-8
 
 

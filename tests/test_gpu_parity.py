@@ -2,7 +2,7 @@
 against the CPU oracle and the reference's golden fixtures.
 
 Bars: SpMV kernels bit-exact vs the oracle's reference-order loops; everything
-that goes through the indirect (PCG, eps_rel = 1e-10) solve within the stated
+that goes through the indirect (PCG, stop 1e-5 x eps of the request, 1e-8 x eps with equality rows) solve within the stated
 fp64 tolerances: iterates/solutions 1e-6 relative (inf norm), objective 1e-8
 relative, identical iteration counts and status.  The reference's own tests use
 1e-4 absolute (tests/osqp_tester.h:9)."""
@@ -303,7 +303,7 @@ def test_invalid_inputs_rejected(gpu_lib):
 ])
 def test_random_qp_matches_oracle(gpu_lib, oracle_mod, n, m, seed, kw):
     """Same seeded problem through the oracle (direct LDL^T) and the HIP engine
-    (PCG, eps_rel 1e-10): identical iteration count, status and rho updates;
+    (PCG at its default stop): identical iteration count, status and rho updates;
     x, y within 1e-6 relative; objective within 1e-8 relative; residuals 1e-4 rel + 1e-9."""
     import osqp_amd
     from osqp_amd.problems import random_sparse_qp
@@ -408,7 +408,7 @@ def test_full_size_config3_config5_match_oracle_golden(gpu_lib, cfg):
         pb, kw, step = portfolio_qp(), dict(adaptive_rho_interval=100), 50
     else:
         pb, kw, step = {k: v for k, v in lasso_qp().items() if k in "PqAlu"}, {}, 20
-    assert osqp_amd.engine_options()["pcg_eps_rel"] == 1e-10
+    assert osqp_amd.engine_options()["pcg_eps_rel"] == 1e-9
     s = osqp_amd.OSQP().setup(**pb, eps_abs=1e-4, eps_rel=1e-4, **kw)
     r = s.solve()
     gi = g["info"]
