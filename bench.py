@@ -114,7 +114,11 @@ def kernel_roofline(solver, reps=300):
                     bytes_per_launch=b_pcg * its, usec_per_launch=round(us, 3), pcg_iterations_per_launch=its,
                     usec_per_pcg_iteration=round(us / max(its, 1), 3),
                     resident=dict(nnzK=int(info[4]), workgroups=int(info[3]), entries_per_thread=int(info[2]), lds_bytes=int(info[5]),
-                                  register_bytes_of_K=int(info[4]) * 10),
+                                  register_bytes_of_K=int(info[4]) * 10,
+                                  # what the launch moves on chip instead of streaming matrices: every CU reads the exchanged vector
+                                  # (rows + riding partials, line-padded) once per PCG iteration
+                                  exchange_bytes_per_iteration=int(info[3]) * (int(info[5]) - 8 * (512 + 61 + 3 + 16 + 5 * 64 + 48)),
+                                  exchange_gbs_l2_to_cus=round(int(info[3]) * (int(info[5]) - 8 * (512 + 61 + 3 + 16 + 5 * 64 + 48)) * its / us / 1e3, 1)),
                     note="one launch = one linear solve: K = P + sigma I + A' rho A (%d entries) sits in the register files of %d CUs, "
                          "each PCG iteration exchanges one n-vector between the workgroups inside the launch; duration = (%d graph-captured "
                          "[k_pcg_init, k_pcg_resident] pairs - the same count of k_pcg_init) / %d, every repetition the same solve of %d PCG "
