@@ -1145,6 +1145,8 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
           }
         }
         if (__all(ok)) break;
+        ++rounds;
+        if (rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }     // clock and give-up word only every 16th round: one load less in most rounds
         const bool late = wall_clock64() - t0 > RES_WAIT_TICKS;
         if (late || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           if (late) {             // leave a note for the host's message: who waited for whom
@@ -1154,7 +1156,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
           if (lane == 0) sc[3] = 1.0;
           break;
         }
-        if ((++rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if ((rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -1245,6 +1247,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
             if ((unsigned)(x >> 32) == tag) { gv[q] = (unsigned)x; pend &= ~(1u << q); }
           }
         if (__all(pend == 0)) break;
+        if (++rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }
         const bool late = wall_clock64() - t0 > RES_WAIT_TICKS;
         if (late || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           if (late) {
@@ -1254,7 +1257,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
           if (lane == 0) sc[3] = 1.0;
           break;
         }
-        if ((++rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // a poll that stays unanswered this long: drop whatever this CU still caches
+        if ((rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // a poll that stays unanswered this long: drop whatever this CU still caches
         __builtin_amdgcn_s_sleep(1);
       }
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;
