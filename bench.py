@@ -78,7 +78,7 @@ def kernel_roofline(solver, reps=300):
                                        note="one PCG iteration = k_cg_A + k_cg_B in loop order; bytes = SURVEY 8(d) B_pcg"))
     L.hipeng_resident_info.restype = C.c_int
     L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
-    info = (C.c_longlong * 8)()
+    info = (C.c_longlong * 10)()
     assert L.hipeng_resident_info(solver.engine(), info) == 0
     if info[1]:
         # Resident engine: ONE launch of k_pcg_resident is the whole linear solve of an ADMM iteration (K in registers,

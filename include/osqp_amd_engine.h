@@ -149,8 +149,9 @@ int hipeng_is_split(hipeng *e);   /* k_cg_A as two launches (update-only + apply
 /* Resident PCG (the reduced matrix K = P + sigma I + A' rho A held in registers, one launch per linear
  * solve; engine.hip, k_pcg_resident).  out[0] structures built, [1] in use, [2] entries of K per thread,
  * [3] workgroups, [4] nnz(K), [5] LDS bytes per workgroup, [6] PCG iterations of the most recent linear
- * solve, [7] pipelined recurrences switched off for the current K. */
-int hipeng_resident_info(hipeng *e, long long out[8]);
+ * solve, [7] pipelined recurrences switched off for the current K, [8] true-residual checks that failed since create
+ * (each continued its solve from the true residual), [9] reserved. */
+int hipeng_resident_info(hipeng *e, long long out[10]);
 /* For the tests: K as the resident kernel holds it, as triplets; returns nnz(K) or a negative code. */
 long long hipeng_resident_dump(hipeng *e, int *row, int *col, double *val, long long cap);
 

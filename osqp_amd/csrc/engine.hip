@@ -113,6 +113,7 @@ struct State {
   int    res_fail;         // resident PCG: a wait timed out (workgroups not co-resident); the host falls back to the launch-per-step path
   int    res_pipe_off;     // resident PCG: the pipelined recurrences failed a true-residual check for this K (k_form_K clears it)
   int    res_ver_cnt;      // resident PCG: solves since K last changed (which of them are checked: k_pcg_resident)
+  int    res_chk_fail;     // resident PCG: true-residual checks that failed since create (each continued the solve from the true residual)
   int    res_dbg[4];       // resident PCG, first timed-out wait: 1 = flags / 2 = granules, exchange number, waiting workgroup, first missing workgroup
 };
 
@@ -1281,14 +1282,16 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   bool conv = false, bad = false, failed = false;
   // One loop, one copy of each exchange (four inlined copies cost 88 spilled registers).  Modes:
   //   0  w = K u0 for the pipelined phase           1  pipelined iteration (Ghysels-Vanroose): ONE exchange -- m = Minv w
-  //   2  true-residual check r0 - K (x - x0)           travels with the partials of (r,u), (w,u), (r,r); wavefront 0 forms
-  //   3  Chronopoulos-Gear iteration with a fresh      the scalars while the others multiply; w and u follow recurrences
+  //   2  true-residual check r0 - K (x - x0) of        travels with the partials of (r,u), (w,u), (r,r); wavefront 0 forms
+  //      EVERY solve that claims convergence           the scalars while the others multiply; w and u follow recurrences
+  //   3  Chronopoulos-Gear iteration with a fresh
   //      product (the recurrences of k_cg_A/k_cg_B)
   // The pipelined recurrences drift on ill-conditioned systems, so: out after 64 iterations, out on any breakdown, and
   // every solve that claims convergence is checked against the true residual.  A failed check hands the solve to
   // mode 3 and switches the pipelined phase off until K changes.
   int mode = pipe ? 0 : 3;
-  int check_why = 0;                   // 0: the recurrence says converged, 1: breakdown / iteration cap, 2: long solve
+  int check_why = 0;                   // 0: the pipelined recurrence says converged, 1: its breakdown / iteration cap, 2: long solve, 3: mode 3 says converged
+  int checks3 = 0;                     // failed checks of mode-3 verdicts in this solve
   bool have_u0 = rc.u0_direct;         // the vector k_pcg_init left in global memory is still the u of the recurrences
   while (true) {
     double val = u_, e0 = 0.0, e1 = 0.0, e2 = 0.0, m_ = 0.0;
@@ -1341,7 +1344,8 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
       // had claimed convergence or broken down (not when the solve was merely long)
       if (own) { r_ = rt; u_ = mi * rt; }
       gam_old = 0.0; alp_old = 0.0;
-      if (g == 0 && t == 0 && check_why != 2) st->res_pipe_off = 1;
+      if (check_why == 3) ++checks3;
+      if (g == 0 && t == 0) { if (check_why != 2) st->res_chk_fail += 1; if (check_why < 2) st->res_pipe_off = 1; }   // (a long solve cut at 64 iterations has not failed anything)
       __syncthreads();          // sc[] is rewritten by the next exchange
       mode = 3;
       continue;
@@ -1350,7 +1354,12 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
     if (!scal_exchange(own ? r_ * u_ : 0.0, own ? w_ * u_ : 0.0, own ? r_ * r_ : 0.0)) { failed = true; break; }
     const double gam = sc[0], del = sc[1], rr = sc[2];
     cs = cg_step(rr, gam, del, gam_old, alp_old, tol2, iters, 0, prm, false);
-    if (cs.stop) { conv = cs.conv; bad = cs.bad && !cs.conv; break; }
+    if (cs.stop) {
+      // a converged solve is checked against the true residual here too (twice at most: on a system whose attainable
+      // accuracy sits above the stop the recursive residual's verdict stands, as on the launch-per-step path)
+      if (cs.conv && checks3 < 2) { check_why = 3; mode = 2; continue; }
+      conv = cs.conv; bad = cs.bad && !cs.conv; break;
+    }
     ++iters; gam_old = gam; alp_old = cs.alpha;
     if (own) {
       p_ = cs.first ? u_ : (u_ + cs.beta * p_);
@@ -2986,14 +2995,15 @@ extern "C" long long hipeng_timeline(hipeng *e, unsigned long long *out, long lo
 extern "C" int hipeng_is_split(hipeng *e) { return e && e->split ? 1 : 0; }
 
 // Resident PCG: out[0] structures built, [1] in use, [2] entries of K per thread, [3] workgroups, [4] nnz(K),
-// [5] LDS bytes per workgroup, [6] PCG iterations of the most recent linear solve, [7] pipelined phase switched off for this K
-extern "C" int hipeng_resident_info(hipeng *e, long long out[8]) {
+// [5] LDS bytes per workgroup, [6] PCG iterations of the most recent linear solve, [7] pipelined phase switched off for this K,
+// [8] true-residual checks that failed since create
+extern "C" int hipeng_resident_info(hipeng *e, long long out[10]) {
   if (!e || !out) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   State s;
   if (read_state(e, &s)) return HIPENG_ERR_HIP;
   out[0] = e->res_on; out[1] = e->res_use; out[2] = e->rc.E; out[3] = e->rc.nwg; out[4] = e->res_nnz; out[5] = (long long)e->res_lds;
-  out[6] = std::max(s.iters[0], s.iters[1]); out[7] = s.res_pipe_off;
+  out[6] = std::max(s.iters[0], s.iters[1]); out[7] = s.res_pipe_off; out[8] = s.res_chk_fail; out[9] = 0;
   return 0;
 }
 
