@@ -112,7 +112,6 @@ struct State {
   unsigned res_epoch;      // resident PCG: tag of the last exchange of the previous launch
   int    res_fail;         // resident PCG: a wait timed out (workgroups not co-resident); the host falls back to the launch-per-step path
   int    res_pipe_off;     // resident PCG: the pipelined recurrences failed a true-residual check for this K (k_form_K clears it)
-  int    res_ver_cnt;      // resident PCG: solves since K last changed (which of them are checked: k_pcg_resident)
   int    res_chk_fail;     // resident PCG: true-residual checks that failed since create (each continued the solve from the true residual)
   int    res_dbg[4];       // resident PCG, first timed-out wait: 1 = flags / 2 = granules, exchange number, waiting workgroup, first missing workgroup
 };
@@ -996,7 +995,7 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const void *p,
 __device__ __forceinline__ int lane_int(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __global__ void __launch_bounds__(TB) k_form_K(Ctx c, ResCtx rc) {
   const double sigma = c.prm->sigma;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { c.st->res_pipe_off = 0; c.st->res_ver_cnt = 0; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) c.st->res_pipe_off = 0;     // a new K: the pipelined recurrences get another chance
   const int lane = threadIdx.x & 63, nwaves = gridDim.x * (TB / 64);
   for (int i = blockIdx.x * (TB / 64) + (threadIdx.x >> 6); i < c.n; i += nwaves) {
     const int e0 = rc.krp[i], e1 = rc.krp[i + 1];
@@ -1068,7 +1067,6 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   const ResWG w = rc.wg[g];
   const Params prm = *c.prm;
   const unsigned ep0 = st->res_epoch;
-  const int ver_cnt = st->res_ver_cnt;  // (checks were sampled by this count at first; that let drifting solves through: 625 instead of 200 ADMM iterations on a cond 1e6 system at eps 1e-9.  Every pipelined solve is checked now.)
   // pipelined recurrences only where a drift would be caught: not in the convexity probe, not after a failed check
   bool pipe = rc.pipe && !st->res_pipe_off && !prm.no_restart;
   // ---- own slice of K into registers (issued first: in flight under everything below) ----
@@ -1398,7 +1396,6 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
     if (bad) st->neg_curv = 1;
     st->tol2 = tol2;
     st->res_epoch = ep0 + (unsigned)nx;
-    st->res_ver_cnt = ver_cnt + 1;
   }
 }
 
