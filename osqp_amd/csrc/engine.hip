@@ -1118,16 +1118,23 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
 
   // Exchange (1): every workgroup's rows of one vector (+ 3 doubles riding along) to every workgroup's LDS.
   // Write-through stores, drain, flag; wavefront 0 polls the flags; sc1 sweep.  False when a wait timed out.
-  auto vec_exchange = [&](double val, double e0, double e1, double e2) __attribute__((always_inline)) -> bool {
+  auto vec_exchange = [&](double val, bool ride) __attribute__((always_inline)) -> bool {
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0;     // riding partials of (r,u), (w,u), (r,r) when `ride`
     ++nx; tag = ep0 + (unsigned)nx; par = (int)(tag & 1u);
     RTL(0);
     const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.ubuf + (size_t)par * npad, (size_t)npad * 8);
     if (wv == 0) {
       // rows at pos .. pos + nr - 1, the three riding partials right behind them: all inside this workgroup's own lines
-      if (lane < w.nr + 3) {
-        const double v = lane < w.nr ? val : (lane == w.nr ? e0 : (lane == w.nr + 1 ? e1 : e2));
-        u32x2 d; d.x = (unsigned)__double2loint(v); d.y = (unsigned)__double2hiint(v);
+      if (lane < w.nr) {
+        u32x2 d; d.x = (unsigned)__double2loint(val); d.y = (unsigned)__double2hiint(val);
         __builtin_amdgcn_raw_buffer_store_b64(d, rs, (w.pos + lane) * 8, 0, AUX_SC1);
+      }
+      // (the partials are reduced while the rows are on their way)
+      if (ride) { e0 = wave_sum(own ? r_ * u_ : 0.0); e1 = wave_sum(own ? w_ * u_ : 0.0); e2 = wave_sum(own ? r_ * r_ : 0.0); }
+      if (lane < 3) {
+        const double v = lane == 0 ? e0 : (lane == 1 ? e1 : e2);
+        u32x2 d; d.x = (unsigned)__double2loint(v); d.y = (unsigned)__double2hiint(v);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rs, (w.pos + w.nr + lane) * 8, 0, AUX_SC1);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(rc.flags + (size_t)g * RES_FSTRIDE, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1292,13 +1299,11 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   int checks3 = 0;                     // failed checks of mode-3 verdicts in this solve
   bool have_u0 = rc.u0_direct;         // the vector k_pcg_init left in global memory is still the u of the recurrences
   while (true) {
-    double val = u_, e0 = 0.0, e1 = 0.0, e2 = 0.0, m_ = 0.0;
-    if (mode == 1) {
-      m_ = mi * w_; val = m_;
-      if (wv == 0) { e0 = wave_sum(own ? r_ * u_ : 0.0); e1 = wave_sum(own ? w_ * u_ : 0.0); e2 = wave_sum(own ? r_ * r_ : 0.0); }
-    } else if (mode == 2) val = x_ - x0_;
+    double val = u_, m_ = 0.0;
+    if (mode == 1) { m_ = mi * w_; val = m_; }
+    else if (mode == 2) val = x_ - x0_;
     if (have_u0) { ++nx; tag = ep0 + (unsigned)nx; par = (int)(tag & 1u); load_u0(); have_u0 = false; }   // (a fresh tag for the granules of exchange (2))
-    else if (!vec_exchange(val, e0, e1, e2)) { failed = true; break; }
+    else if (!vec_exchange(val, mode == 1)) { failed = true; break; }
     WTL(0);
     products_issue();
     WTL(1);
