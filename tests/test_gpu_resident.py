@@ -151,6 +151,21 @@ def test_resident_on_tiny_problems(gpu_lib, oracle_mod):
         assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
 
 
+def test_resident_with_many_entries_per_thread(gpu_lib, oracle_mod):
+    """A dense K (n = 1800: 3.2 M entries, 48 per thread): the instantiations with 32 and more entries per thread keep part of
+    K in scratch memory; same results."""
+    import osqp_amd
+    pb = _qp(1800, 300, 60, eq=30, dens=0.03)
+    kw = dict(eps_abs=1e-5, eps_rel=1e-5)
+    sg = osqp_amd.OSQP().setup(**pb, **kw); so = oracle_mod.OracleOSQP().setup(**pb, **kw)
+    inf = _info(sg)
+    assert inf["in_use"] and inf["E"] >= 32, inf
+    rg, ro = sg.solve(), so.solve()
+    assert rg.info.status == ro.info.status == "solved" and rg.info.iter == ro.info.iter
+    assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
+    assert _info(sg)["in_use"]
+
+
 def test_resident_off_by_environment_and_for_large_n(gpu_lib):
     import osqp_amd
     pb = _qp(400, 300, 50)
