@@ -935,17 +935,21 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
 // Resident PCG: the whole linear solve of one ADMM iteration in ONE launch.
 //
 // For problems whose reduced matrix K = P + sigma I + A' diag(rho) A fits the chip's register files
-// (n <= 16384, nnz(K) <= 256 workgroups x 512 threads x 64 entries) every workgroup keeps a block of
-// rows of K -- values and 16-bit column ids -- in registers for the whole solve, one workgroup per CU.
-// A Chronopoulos-Gear iteration then needs two exchanges between the workgroups instead of two kernel
-// boundaries with their re-streaming of A and M:
-//   (1) the vector u = Minv r: every workgroup stores its rows write-through (sc1), drains, raises its
-//       flag; one wavefront polls the 256 flags; then all wavefronts read the n doubles into LDS with
-//       L1-bypassing (sc1) loads -- no fence (MI355X_MICROARCH.md, visibility: the flag/sc1 row);
-//   (2) the three dot partials per workgroup as 16-byte {value, tag} granules: the data is the flag.
-// Measured in tools/exchange_probe.hip: 4.6 us for (1) at n = 10000 against 12.2 us for a k_cg_A/k_cg_B pair.
-// The recurrences, the stop rule and the scalars are those of k_cg_A / k_cg_B (cg_step); the operator is the
-// explicit K (k_form_K re-forms its values whenever rho, sigma or the matrices change).
+// (n <= 15616, nnz(K) <= 256 workgroups x 448 threads x 64 entries) every workgroup keeps a block of
+// rows of K -- values and 16-bit column positions -- in registers for the whole solve, one workgroup per CU:
+// wavefronts 1..7 hold the entries and multiply, wavefront 0 owns the rows' vector elements, decides and talks.
+// The workgroups exchange vectors through memory INSIDE the launch instead of ending a kernel:
+//   (1) an n-vector: every workgroup stores its rows write-through (sc1), drains, raises its flag; wavefront 0
+//       polls the 256 flags; then all wavefronts read the vector into LDS with L1-bypassing (sc1) loads -- no
+//       fence (MI355X_MICROARCH.md, visibility: the flag/sc1 row).  3.5 us alone (tools/exchange_probe.hip),
+//       4.6 us in the loop, against 12.2 us for a k_cg_A/k_cg_B pair;
+//   (2) three scalars per workgroup as 8-byte {32 bits, tag} granules, stored and polled with agent-scope atomics.
+// Rules the protocol learned the hard way: no 128-byte line of an exchange buffer is written by two
+// CUs; a tag never shares a 16-byte store with data it vouches for in the other half; polls are 4- or 8-byte atomic
+// loads, never 16-byte buffer loads.
+// Recurrences: pipelined CG (Ghysels-Vanroose, ONE exchange per iteration) as long as its true-residual checks
+// pass, else Chronopoulos-Gear with a fresh product (the recurrences, scalars and stop rule of k_cg_A / k_cg_B:
+// cg_step).  The operator is the explicit K (k_form_K re-forms its values whenever rho, sigma or the matrices change).
 // Every wait is bounded in time: if the grid is not co-resident (another process or stream holds CUs) the
 // launch gives up, sets State::res_fail, and the host continues with the launch-per-step kernels.
 // ---------------------------------------------------------------------------
@@ -2040,7 +2044,7 @@ static int build_resident(hipeng *e) {
   if (const char *x = getenv("OSQP_AMD_RESIDENT")) want = atoi(x);
   if (const char *x = getenv("OSQP_AMD_RESIDENT_MIN_N")) min_n = atoi(x);
   if (!want) RES_NO("OSQP_AMD_RESIDENT=0");
-  if (n < min_n || n > RES_MAXN) RES_NO("n outside [OSQP_AMD_RESIDENT_MIN_N, 16384]");
+  if (n < min_n || n > RES_MAXN) RES_NO("n outside [OSQP_AMD_RESIDENT_MIN_N, 15616]");
   if (!e->hrows.empty() || e->A.nwave < (int)e->A.blk.size()) RES_NO("A has rows of 8192 or more entries");   // (their outer products alone overflow the register files)
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, e->device));
