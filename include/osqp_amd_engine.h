@@ -150,8 +150,10 @@ int hipeng_is_split(hipeng *e);   /* k_cg_A as two launches (update-only + apply
  * solve; engine.hip, k_pcg_resident).  out[0] structures built, [1] in use, [2] entries of K per thread,
  * [3] workgroups, [4] nnz(K), [5] LDS bytes per workgroup, [6] PCG iterations of the most recent linear
  * solve, [7] pipelined recurrences switched off for the current K, [8] true-residual checks that failed since create
- * (each continued its solve from the true residual), [9] reserved. */
-int hipeng_resident_info(hipeng *e, long long out[10]);
+ * (each continued its solve from the true residual), [9] form (1: k_pcg_resident, 2: k_pcg_blockres), [10] launches that
+ * gave up waiting (each sends the rest of its run_admm call to the launch-per-step kernels; the third ends the mode for this
+ * engine), [11] reserved.  [1] stays 1 until that third one. */
+int hipeng_resident_info(hipeng *e, long long out[12]);
 /* For the tests: K as the resident kernel holds it, as triplets; returns nnz(K) or a negative code. */
 long long hipeng_resident_dump(hipeng *e, int *row, int *col, double *val, long long cap);
 

@@ -1056,9 +1056,10 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   if (st->stalled || !st->run || st->res_fail) return;
   double *uv = rlds;                              // npad doubles: the exchanged vector (rows and riding partials of every workgroup)
   double *seg = uv + rc.npad;                     // RES_TB + RES_MAXROWS row-segment sums
-  double *sc = seg + RES_TB + RES_MAXROWS;        // 4 doubles: gamma, delta, rr, fail word
+  double *sc = seg + RES_TB + RES_MAXROWS;        // 8 doubles: gamma, delta, rr, fail word, verdict
+  double *sval = sc + 8;                          // 3 x 256: the workgroups' dot partials during exchange (2)
 #ifdef OSQP_AMD_TIMELINE
-  long long *tls = reinterpret_cast<long long *>(sc + 8);   // phase stamps of the first 64 exchanges (workgroup 0)
+  long long *tls = reinterpret_cast<long long *>(sval + 768);   // phase stamps of the first 64 exchanges (workgroup 0)
 #define RTL(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && nx >= 1 && nx <= 64) tls[(nx - 1) * 5 + (k)] = wall_clock64(); } while (0)
   long long *wtl = tls + 5 * 64;                             // [phase][wavefront] stamps of exchange 8 (workgroup 0)
 #define WTL(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && nx == 8) wtl[(k) * 8 + (threadIdx.x >> 6)] = wall_clock64(); } while (0)
@@ -1142,26 +1143,27 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(rc.flags + (size_t)g * RES_FSTRIDE, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wv < 4) {
+      // wavefronts 0..3 poll the 256 flags, ONE flag per lane: a lane that polled four flags waited for each load
+      // before it issued the next (the compiler keeps atomic loads in order), four round trips per look
+      const int o = t;                         // flag of workgroup t
       const long long t0 = wall_clock64();
       unsigned rounds = 0;
       while (true) {
         bool ok = true;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int o = lane + 64 * q;
-          if (o < nwg) {
-            const unsigned f = __hip_atomic_load(rc.flags + (size_t)o * RES_FSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok &= (int)(f - tag) >= 0;
-          }
+        if (o < nwg) {
+          const unsigned f = __hip_atomic_load(rc.flags + (size_t)o * RES_FSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = (int)(f - tag) >= 0;
         }
         if (__all(ok)) break;
         ++rounds;
-        if (rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }     // clock and give-up word only every 16th round: one load less in most rounds
+        if (rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }     // clock and give-up word only every 16th round
         const bool late = wall_clock64() - t0 > RES_WAIT_TICKS;
         if (late || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           if (late) {             // leave a note for the host's message: who waited for whom
             const unsigned long long miss = __ballot(!ok);
-            if (lane == 0 && atomicCAS(&st->res_dbg[0], 0, 1) == 0) { st->res_dbg[1] = nx; st->res_dbg[2] = g; st->res_dbg[3] = miss ? (int)__ffsll((long long)miss) - 1 : -1; }
+            if (lane == 0 && atomicCAS(&st->res_dbg[0], 0, 1) == 0) { st->res_dbg[1] = nx; st->res_dbg[2] = g; st->res_dbg[3] = miss ? 64 * wv + (int)__ffsll((long long)miss) - 1 : -1; }
           }
           if (lane == 0) sc[3] = 1.0;
           break;
@@ -1233,36 +1235,43 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   };
   // Exchange (2): three dot partials per workgroup as tagged granules (the data is the flag); totals in sc[0..2].
   auto scal_exchange = [&](double pg, double pd, double prr) __attribute__((always_inline)) -> bool {
+    // granules of 8 bytes {32 bits of data, tag}: six per workgroup, in a line of the workgroup's own; stored and read
+    // with agent-scope atomic accesses; ONE workgroup's six per thread of wavefronts 0..3 (the compiler keeps atomic
+    // loads in order: when one wavefront swept everything a look took 24 round trips)
+    unsigned long long *gb = reinterpret_cast<unsigned long long *>(rc.sbuf) + (size_t)par * nwg * RES_GSTRIDE;
     if (wv == 0) {
       pg = wave_sum(pg); pd = wave_sum(pd); prr = wave_sum(prr);
-      // granules of 8 bytes {32 bits of data, tag}, stored and polled with agent-scope atomic accesses
-      // (global_store/load_dwordx2 sc1): six per workgroup, in a line of the workgroup's own
-      unsigned long long *gb = reinterpret_cast<unsigned long long *>(rc.sbuf) + (size_t)par * nwg * RES_GSTRIDE;
       if (lane < 6) {
         const double v = lane < 2 ? pg : (lane < 4 ? pd : prr);
         const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
         __hip_atomic_store(gb + (size_t)g * RES_GSTRIDE + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      unsigned pend = 0;                     // bit 6 q + c: granule c of workgroup lane + 64 q still missing
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if (lane + 64 * q < nwg) pend |= 63u << (6 * q);
-      unsigned gv[24];
+    }
+    if (wv < 4) {
+      const int o = t;                         // the workgroup whose granules this thread fetches
+      unsigned pend = o < nwg ? 63u : 0u;
+      unsigned gv[6];
       const long long t0 = wall_clock64();
       unsigned rounds = 0;
       while (true) {
+        // (agent-scope atomic loads, global_load_dwordx2 sc1, one after the other: sweeps with buffer_load_dwordx2/x4 sc1 --
+        // several loads of one line in flight while its write arrives -- left, once in ~1e5 exchanges, a few workgroups of
+        // ONE XCD reading the old line for good while the other 249 had moved on; reading with atomic OR / compare-and-swap
+        // once a poll looks stuck is worse: those write, and lost the owner's store now and then)
 #pragma unroll
-        for (int q = 0; q < 24; ++q)
+        for (int q = 0; q < 6; ++q)
           if (pend & (1u << q)) {
-            const unsigned long long x = __hip_atomic_load(gb + (size_t)(lane + 64 * (q / 6)) * RES_GSTRIDE + (q % 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(x >> 32) == tag) { gv[q] = (unsigned)x; pend &= ~(1u << q); }
+            const unsigned long long v = __hip_atomic_load(gb + (size_t)o * RES_GSTRIDE + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == tag) { gv[q] = (unsigned)v; pend &= ~(1u << q); }
           }
         if (__all(pend == 0)) break;
+        asm volatile("" ::: "memory");
         if (++rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }
         const bool late = wall_clock64() - t0 > RES_WAIT_TICKS;
         if (late || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           if (late) {
             const unsigned long long miss = __ballot(pend != 0);
-            if (lane == 0 && atomicCAS(&st->res_dbg[0], 0, 2) == 0) { st->res_dbg[1] = nx; st->res_dbg[2] = g; st->res_dbg[3] = miss ? (int)__ffsll((long long)miss) - 1 : -1; }
+            if (lane == 0 && atomicCAS(&st->res_dbg[0], 0, 2) == 0) { st->res_dbg[1] = nx; st->res_dbg[2] = g; st->res_dbg[3] = miss ? 64 * wv + (int)__ffsll((long long)miss) - 1 : -1; }
           }
           if (lane == 0) sc[3] = 1.0;
           break;
@@ -1270,14 +1279,18 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
         if ((rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // a poll that stays unanswered this long: drop whatever this CU still caches
         __builtin_amdgcn_s_sleep(1);
       }
+      if (o < nwg) {
+        sval[3 * o] = __hiloint2double((int)gv[1], (int)gv[0]);
+        sval[3 * o + 1] = __hiloint2double((int)gv[3], (int)gv[2]);
+        sval[3 * o + 2] = __hiloint2double((int)gv[5], (int)gv[4]);
+      }
+    }
+    __syncthreads();
+    if (wv == 0) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (lane + 64 * q < nwg) {
-          a0 += __hiloint2double((int)gv[6 * q + 1], (int)gv[6 * q]);
-          a1 += __hiloint2double((int)gv[6 * q + 3], (int)gv[6 * q + 2]);
-          a2 += __hiloint2double((int)gv[6 * q + 5], (int)gv[6 * q + 4]);
-        }
+        if (lane + 64 * q < nwg) { a0 += sval[3 * (lane + 64 * q)]; a1 += sval[3 * (lane + 64 * q) + 1]; a2 += sval[3 * (lane + 64 * q) + 2]; }
       a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
       if (lane == 0) { sc[0] = a0; sc[1] = a1; sc[2] = a2; }
     }
@@ -1399,6 +1412,181 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
     }
   }
 #endif
+  if (g == 0 && t == 0) {
+    st->iters[0] = iters; st->iters[1] = 0;
+    st->done = conv ? 1 : 2;
+    if (bad) st->neg_curv = 1;
+    st->tol2 = tol2;
+    st->res_epoch = ep0 + (unsigned)nx;
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// Block-resident PCG: the resident idea for the portfolio family (BASELINE config 5), whose n = 50 000 is far beyond
+// the vector exchange of k_pcg_resident -- and which needs none.  If P consists of dense diagonal blocks only and every
+// row of A either has a single entry (bounds) or is one of at most four huge rows (a budget constraint), then
+//     K = blockdiag(P_b + sigma I + diag(sum_i rho_i a_ij^2))  +  sum_h rho_h a_h a_h'
+// and a workgroup that owns whole blocks needs nobody else's vector elements: K_b u_b is a dense product from registers
+// (each row of a block split over two threads, 64 entries each), the low-rank part needs the scalars s_h = a_h'u, and
+// delta = (Ku, u) = sum_g (K_b u_b, u_b) + sum_h rho_h s_h^2.  So ONE exchange of 3 + nh scalars per workgroup and
+// iteration (tagged 8-byte granules, the exchange (2) of k_pcg_resident) carries gamma, delta', ||r||^2 and the s_h;
+// everything else is local.  Chronopoulos-Gear recurrences with a fresh product (cg_step), 3 barriers per iteration.
+// The 50 MB of blocks are read once per launch instead of once per PCG iteration.
+// ---------------------------------------------------------------------------
+struct BrCtx { int nwg; const int *blk0; double *sbuf; };
+
+template <int NH>
+__global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
+  constexpr int NV = 3 + NH;                 // scalars per workgroup and iteration
+  __shared__ double ul[256];                 // u of the own rows
+  __shared__ double red[8 * 8];              // per-wavefront partials
+  __shared__ double tot[8];                  // totals; [7]: a wait timed out
+  __shared__ double sval[256 * NV];          // every workgroup's scalars during the exchange
+  State *st = c.st;
+  if (st->stalled || !st->run || st->res_fail) return;
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6, nwg = bc.nwg;
+  const Params prm = *c.prm;
+  const unsigned ep0 = st->res_epoch;
+  // the row of this thread pair: row rl of the workgroup's (at most two) blocks, columns [64 h, 64 h + 64) of its block
+  const int rl = t >> 1, h = t & 1;
+  int j = -1, cb = 0, bw = 0, c0 = 0, pitch = 0; size_t off = 0;
+  {
+    int base = 0;
+    for (int q = bc.blk0[g]; q < bc.blk0[g + 1]; ++q) {
+      const DenseBlk d = c.dP.blk[q];
+      if (rl >= base && rl < base + d.b) { j = d.c0 + (rl - base); cb = base; bw = d.b; c0 = d.c0; off = (size_t)d.off; pitch = d.pitch; }
+      base += d.b;
+    }
+  }
+  const bool row = j >= 0, own = row && h == 0;
+  double dadd = 0.0, hc[NH > 0 ? NH : 1], hrho[NH > 0 ? NH : 1];
+#pragma unroll
+  for (int q = 0; q < NH; ++q) { hc[q] = 0.0; hrho[q] = c.rho[c.hrow[q]]; }
+  if (row) {
+    dadd = prm.sigma;
+    for (int k = c.M.split[j]; k < c.M.rowptr[j + 1]; ++k) {          // single-entry rows of A at this column
+      const int i = c.M.col[k] - c.n;
+      bool huge = false;
+#pragma unroll
+      for (int q = 0; q < NH; ++q) huge |= i == c.hrow[q];
+      if (!huge) { const double a = c.M.val[k]; dadd += c.rho[i] * a * a; }
+    }
+#pragma unroll
+    for (int q = 0; q < NH; ++q) hc[q] = c.hcol[(size_t)q * c.n + j];
+  }
+  double kv[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    const int cc = h * 64 + k;
+    // K_b is symmetric: entry (row, cc) is read as (cc, row), so that the lanes of a wave instruction -- consecutive rows --
+    // read consecutive addresses (row-wise it was one 64-byte segment per lane: 100 us per launch)
+    kv[k] = (row && cc < bw) ? c.dP.val[off + (size_t)cc * pitch + (j - c0)] + (cc == j - c0 ? dadd : 0.0) : 0.0;
+  }
+  double rr0 = 0.0, bb = 0.0;
+  for (int i = lane; i < c.gridM; i += 64) { rr0 += c.part_rr[i]; bb += c.part_bb[i]; }
+  rr0 = wave_sum(rr0); bb = wave_sum(bb);
+  const double tol2 = fmax(prm.eps_rel * prm.eps_rel * bb, prm.eps_abs * prm.eps_abs);
+  if (rr0 <= tol2) {
+    if (g == 0 && t == 0) { st->done = 1; st->tol2 = tol2; }
+    return;
+  }
+  double r_ = 0, u_ = 0, p_ = 0, s_ = 0, x_ = 0, mi = 0;
+  if (own) { r_ = c.init_r[(size_t)j * c.init_stride]; u_ = c.init_z[j]; x_ = c.vx[j]; mi = c.minv[j]; }
+  if (t < 256) ul[t] = 0.0;
+  if (t == 0) tot[7] = 0.0;
+  __syncthreads();
+  double gam_old = 0.0, alp_old = 0.0;
+  int iters = 0, nx = 0;
+  bool conv = false, bad = false, failed = false;
+  while (true) {
+    ++nx;
+    const unsigned tag = ep0 + (unsigned)nx;
+    const int par = (int)(tag & 1u);
+    if (own) ul[rl] = u_;
+    __syncthreads();
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) acc += kv[k] * ul[cb + h * 64 + k];
+    acc += dpp_move<0xB1>(acc);                      // the two halves of the row
+    double v[NV];
+    v[0] = own ? r_ * u_ : 0.0; v[1] = own ? acc * u_ : 0.0; v[2] = own ? r_ * r_ : 0.0;
+#pragma unroll
+    for (int q = 0; q < NH; ++q) v[3 + q] = own ? hc[q] * u_ : 0.0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const double w_ = wave_sum(v[i]); if (lane == 0) red[wv * 8 + i] = w_; }
+    __syncthreads();
+    unsigned long long *gb = reinterpret_cast<unsigned long long *>(bc.sbuf) + (size_t)par * nwg * RES_GSTRIDE;
+    if (wv == 0 && lane < 2 * NV) {
+      const int i = lane >> 1;
+      double sv = 0.0;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) sv += red[w8 * 8 + i];
+      const unsigned half = (lane & 1) ? (unsigned)__double2hiint(sv) : (unsigned)__double2loint(sv);
+      __hip_atomic_store(gb + (size_t)g * RES_GSTRIDE + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wv < 4) {
+      // one workgroup's 2 NV granules per thread of wavefronts 0..3
+      const int o = t;
+      unsigned pend = o < nwg ? (1u << (2 * NV)) - 1u : 0u;
+      unsigned gv[2 * NV];
+      const long long t0 = wall_clock64();
+      unsigned rounds = 0;
+      while (true) {
+#pragma unroll
+        for (int q = 0; q < 2 * NV; ++q)          // agent-scope atomic loads (see k_pcg_resident on why not buffer loads)
+          if (pend & (1u << q)) {
+            const unsigned long long v = __hip_atomic_load(gb + (size_t)o * RES_GSTRIDE + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == tag) { gv[q] = (unsigned)v; pend &= ~(1u << q); }
+          }
+        if (__all(pend == 0)) break;
+        asm volatile("" ::: "memory");
+        if (++rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }
+        if (wall_clock64() - t0 > RES_WAIT_TICKS || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) tot[7] = 1.0; break; }
+        if ((rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (o < nwg) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sval[NV * o + i] = __hiloint2double((int)gv[2 * i + 1], (int)gv[2 * i]);
+      }
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (lane + 64 * q < nwg) a += sval[NV * (lane + 64 * q) + i];
+        a = wave_sum(a);
+        if (lane == 0) tot[i] = a;
+      }
+    }
+    __syncthreads();
+    if (tot[7] != 0.0) { failed = true; break; }
+    const double gam = tot[0], rr = tot[2];
+    double del = tot[1];
+#pragma unroll
+    for (int q = 0; q < NH; ++q) del += hrho[q] * (tot[3 + q] * tot[3 + q]);
+    const CgStep cs = cg_step(rr, gam, del, gam_old, alp_old, tol2, iters, 0, prm, false);
+    if (cs.stop) { conv = cs.conv; bad = cs.bad && !cs.conv; break; }
+    ++iters; gam_old = gam; alp_old = cs.alpha;
+    if (own) {
+      double w_ = acc;
+#pragma unroll
+      for (int q = 0; q < NH; ++q) w_ += (hrho[q] * tot[3 + q]) * hc[q];
+      p_ = cs.first ? u_ : (u_ + cs.beta * p_);
+      s_ = cs.first ? w_ : (w_ + cs.beta * s_);
+      x_ += cs.alpha * p_;
+      r_ -= cs.alpha * s_;
+      u_ = mi * r_;
+    }
+  }
+  if (failed) {
+    if (t == 0) __hip_atomic_store(&st->res_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (own && iters > 0) c.va[j] = x_;
   if (g == 0 && t == 0) {
     st->iters[0] = iters; st->iters[1] = 0;
     st->done = conv ? 1 : 2;
@@ -1789,8 +1977,12 @@ struct hipeng {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   long long admm_done_seen = 0;
   bool res_on = false;       // resident PCG structures built (problem fits the register files)
-  bool res_use = false;      // ... and in use (cleared for good when a launch found the grid not co-resident)
+  bool res_use = false;      // ... and in use
+  int res_fails = 0;         // launches that gave up waiting (one sends the rest of the run_admm call to the launch-per-step
+                             // kernels; the third sends the engine there for good)
   ResCtx rc{};
+  BrCtx bc{};                // block-resident form (res_kind 2)
+  int res_kind = 0;          // 0: launch-per-step only, 1: k_pcg_resident, 2: k_pcg_blockres
   size_t res_lds = 0;
   long long res_nnz = 0;
 };
@@ -1800,6 +1992,23 @@ static int dev_alloc(hipeng *e, T **p, size_t count) {
   void *q = nullptr;
   if (count == 0) count = 1;
   HIPCHK(hipMalloc(&q, count * sizeof(T)));
+  HIPCHK(hipMemsetAsync(q, 0, count * sizeof(T), e->stream));
+  e->allocs.push_back(q);
+  *p = static_cast<T *>(q);
+  return 0;
+}
+
+// Words that one CU polls while another writes them (exchange flags, tagged granules) live in fine-grained memory:
+// in ordinary device memory an XCD's L2 can keep an old copy of such a line for good (a whole XCD then polls the old
+// value while the others have moved on: seen about once in 1e5 exchanges, with every kind of load).
+// OSQP_AMD_RESIDENT_FINE=0 allocates them like everything else.
+template <typename T>
+static int dev_alloc_polled(hipeng *e, T **p, size_t count) {
+  static const int fine = getenv("OSQP_AMD_RESIDENT_FINE") ? atoi(getenv("OSQP_AMD_RESIDENT_FINE")) : 1;
+  if (!fine) return dev_alloc(e, p, count);
+  void *q = nullptr;
+  if (count == 0) count = 1;
+  HIPCHK(hipExtMallocWithFlags(&q, count * sizeof(T), fine == 2 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
   HIPCHK(hipMemsetAsync(q, 0, count * sizeof(T), e->stream));
   e->allocs.push_back(q);
   *p = static_cast<T *>(q);
@@ -2023,6 +2232,17 @@ template <int E> static int res_set_lds(size_t lds) {
   return 0;
 }
 static void launch_resident(hipeng *e) {
+  if (e->res_kind == 2) {
+    const dim3 g2(e->bc.nwg), b2(RES_TB);
+    switch (e->c.nh) {
+      case 0: hipLaunchKernelGGL(k_pcg_blockres<0>, g2, b2, 0, e->stream, e->c, e->bc); break;
+      case 1: hipLaunchKernelGGL(k_pcg_blockres<1>, g2, b2, 0, e->stream, e->c, e->bc); break;
+      case 2: hipLaunchKernelGGL(k_pcg_blockres<2>, g2, b2, 0, e->stream, e->c, e->bc); break;
+      case 3: hipLaunchKernelGGL(k_pcg_blockres<3>, g2, b2, 0, e->stream, e->c, e->bc); break;
+      default: hipLaunchKernelGGL(k_pcg_blockres<4>, g2, b2, 0, e->stream, e->c, e->bc); break;
+    }
+    return;
+  }
   const dim3 g(e->rc.nwg), b(RES_TB);
   switch (e->rc.E) {
     case 8:  hipLaunchKernelGGL(k_pcg_resident<8>,  g, b, e->res_lds, e->stream, e->c, e->rc); break;
@@ -2191,14 +2411,14 @@ static int build_resident(hipeng *e) {
       dev_alloc(e, &d_krp, Kptr.size()) || dev_alloc(e, &d_kcj, Kcol.size()) || dev_alloc(e, &d_kps, Kps.size()) || dev_alloc(e, &d_kdst, kdst.size()) ||
       dev_alloc(e, &d_brk, brk.size()) || dev_alloc(e, &d_slot0, slot0.size()) ||
       dev_alloc(e, &d_segrow, segrow.size()) || dev_alloc(e, &d_rowpos, rowpos.size()) || dev_alloc(e, &rc.ubuf, (size_t)2 * rc.npad) ||
-      dev_alloc(e, &rc.flags, (size_t)nwg * RES_FSTRIDE) || dev_alloc(e, &rc.dbg, (size_t)nwg * 4) || dev_alloc(e, &rc.sbuf, (size_t)2 * nwg * RES_GSTRIDE)) return HIPENG_ERR_HIP;
+      dev_alloc_polled(e, &rc.flags, (size_t)nwg * RES_FSTRIDE) || dev_alloc(e, &rc.dbg, (size_t)nwg * 4) || dev_alloc_polled(e, &rc.sbuf, (size_t)2 * nwg * RES_GSTRIDE)) return HIPENG_ERR_HIP;
 #define UP(dst, src) HIPCHK(hipMemcpyAsync(dst, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, e->stream))
   UP(d_wg, wg); UP(d_rowpos, rowpos); UP(d_col, col); UP(d_rowl, rowl); UP(d_krp, Kptr); UP(d_kcj, Kcol); UP(d_kps, Kps); UP(d_kdst, kdst); UP(d_brk, brk); UP(d_slot0, slot0); UP(d_segrow, segrow);
 #undef UP
   HIPCHK(hipStreamSynchronize(e->stream));       // the sources are locals
   rc.wg = d_wg; rc.rowpos = d_rowpos; rc.col = d_col; rc.rowl = d_rowl; rc.krp = d_krp; rc.kcj = d_kcj; rc.kps = d_kps; rc.kdst = d_kdst; rc.brk = d_brk; rc.slot0 = d_slot0; rc.segrow = d_segrow;
   e->rc = rc;
-  e->res_lds = ((size_t)rc.npad + RES_TB + RES_MAXROWS + 3 + 16 + 5 * 64 + 48) * sizeof(double);   // + phase stamps of the TIMELINE build
+  e->res_lds = ((size_t)rc.npad + RES_TB + RES_MAXROWS + 3 + 16 + 768 + 5 * 64 + 48) * sizeof(double);   // + phase stamps of the TIMELINE build
   int rcode = 0;
   switch (E) {
     case 8: rcode = res_set_lds<8>(e->res_lds); break;   case 16: rcode = res_set_lds<16>(e->res_lds); break;
@@ -2218,6 +2438,54 @@ static int build_resident(hipeng *e) {
   return 0;
 }
 
+
+// Block-resident form (k_pcg_blockres): P = dense diagonal blocks only, rows of A single-entry or folded huge rows.
+static int build_blockres(hipeng *e) {
+  const int n = e->n;
+  int want = 1;
+  if (const char *x = getenv("OSQP_AMD_RESIDENT")) want = atoi(x);
+  if (const char *x = getenv("OSQP_AMD_RESIDENT_BLOCKS")) want = want && atoi(x);
+  if (!want || e->dP_blks.empty()) return 0;
+  // the blocks tile 0..n
+  int next = 0;
+  for (const DenseBlk &d : e->dP_blks) { if (d.c0 != next || d.b > DENSE_MAX) return 0; next += d.b; }
+  if (next != n) return 0;
+  // rows of A: one entry each, except the folded huge rows (all of the huge ones must be folded)
+  if ((int)e->A.blk.size() - e->A.nwave != (int)e->hrows.size()) return 0;
+  std::vector<char> ishuge(std::max(1, e->m), 0);
+  for (int hr : e->hrows) ishuge[hr] = 1;
+  for (int i = 0; i < e->m; i++) if (!ishuge[i] && e->A.rowptr[i + 1] - e->A.rowptr[i] != 1) return 0;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, e->device));
+  const int nwg = std::min(256, prop.multiProcessorCount);
+  const int nb = (int)e->dP_blks.size();
+  if (nb > 2 * nwg) RES_NO("more than two dense blocks per CU");
+  // contiguous blocks, at most two and at most 256 rows per workgroup, spread evenly
+  std::vector<int> blk0(nwg + 1, nb);
+  {
+    int q = 0;
+    for (int g = 0; g < nwg; g++) {
+      blk0[g] = q;
+      const int upto = (int)(((long long)nb * (g + 1) + nwg - 1) / nwg);
+      int rows = 0, cnt = 0;
+      while (q < nb && q < upto && cnt < 2 && rows + e->dP_blks[q].b <= 256) { rows += e->dP_blks[q].b; q++; cnt++; }
+    }
+    blk0[nwg] = q;
+    if (q != nb) RES_NO("the dense blocks do not fit two per workgroup");
+  }
+  BrCtx bc{};
+  bc.nwg = nwg;
+  int *d_blk0 = nullptr;
+  if (dev_alloc(e, &d_blk0, blk0.size()) || dev_alloc_polled(e, &bc.sbuf, (size_t)2 * nwg * RES_GSTRIDE)) return HIPENG_ERR_HIP;
+  HIPCHK(hipMemcpyAsync(d_blk0, blk0.data(), blk0.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  bc.blk0 = d_blk0;
+  e->bc = bc;
+  e->res_kind = 2; e->res_on = e->res_use = true;
+  if (e->trace) fprintf(stderr, "[osqp_amd] block-resident PCG: %d dense blocks over %d workgroups, %d huge rows of A as rank-one terms\n", nb, nwg, (int)e->hrows.size());
+  return 0;
+}
+
 static int elem_grid(int cnt) {
   int g = (cnt + TB - 1) / TB;
   return std::max(1, std::min(g, MAX_PARTS));
@@ -2226,7 +2494,7 @@ static int elem_grid(int cnt) {
 // Everything derived from (P, A, rho, sigma): the Jacobi preconditioner.
 static void refresh_operator(hipeng *e) {
   hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
-  if (e->res_on) hipLaunchKernelGGL(k_form_K, dim3(std::min(2048, (e->n + 3) / 4)), dim3(TB), 0, e->stream, e->c, e->rc);
+  if (e->res_kind == 1) hipLaunchKernelGGL(k_form_K, dim3(std::min(2048, (e->n + 3) / 4)), dim3(TB), 0, e->stream, e->c, e->rc);
 }
 
 // The PCG start vector history is void (cold/warm start from the host, new rho, new matrices):
@@ -2362,7 +2630,8 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
       upload_vec(e, c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
   e->stats.kernels_per_pcg_iter = 2;
   *out = e;
-  if (int rc = build_resident(e)) return rc;
+  if (int rc = build_blockres(e)) return rc;
+  if (!e->res_on) { if (int rc = build_resident(e)) return rc; if (e->res_on) e->res_kind = 1; }
   if (rho_vec) { int rc = hipeng_upload_rho(e, rho_vec); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
@@ -2693,6 +2962,10 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   // admm_done only moves inside this function: the host keeps its own copy, so a call starts
   // without a device round trip.  The device stops starting iterations at admm_target.
   if (count == 0) return 0;
+  // A launch that gave up (a wait timed out) took the rest of that call to the launch-per-step kernels.  Apart from a GPU
+  // that is shared for good, there is a rare transient (about one exchange in 1e5 on small, fast problems: a workgroup's
+  // flag or granule stays invisible to some CUs): the next call tries resident launches again, three strikes end that.
+  if (e->res_on && !e->res_use && e->res_fails < 3) e->res_use = true;
   const long long start = e->admm_total, target = start + (long long)count;
   *e->h_target = target;
   HIPCHK(hipMemcpyAsync(&e->c.st->admm_target, e->h_target, sizeof(long long), hipMemcpyHostToDevice, e->stream));
@@ -2731,9 +3004,9 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     if (s.res_fail) {
       // the resident launch found its grid not co-resident (the GPU is shared): launch-per-step kernels from here on
       fprintf(stderr, "osqp_amd: resident PCG launch timed out waiting for its workgroups (GPU shared with another stream or process?); "
-                      "continuing with the launch-per-step path [wait %d of exchange %d: workgroup %d missed workgroup %d (+64k); PCG iterations so far %d]\n",
-              s.res_dbg[0], s.res_dbg[1], s.res_dbg[2], s.res_dbg[3], std::max(s.iters[0], s.iters[1]));
-      {   // where every workgroup stood when it gave up
+                      "%s with the launch-per-step kernels [wait %d of exchange %d: workgroup %d missed workgroup %d; PCG iterations so far %d]\n",
+              e->res_fails >= 2 ? "continuing for good" : "finishing this window", s.res_dbg[0], s.res_dbg[1], s.res_dbg[2], s.res_dbg[3], std::max(s.iters[0], s.iters[1]));
+      if (e->res_kind == 1) {   // where every workgroup stood when it gave up
         std::vector<int> d((size_t)e->rc.nwg * 4), fl((size_t)e->rc.nwg * RES_FSTRIDE);
         if (hipMemcpy(d.data(), e->rc.dbg, d.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess &&
             hipMemcpy(fl.data(), e->rc.flags, fl.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -2752,6 +3025,7 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
         }
       }
       e->res_use = false;
+      e->res_fails += 1;
       HIPCHK(hipMemsetAsync(&e->c.st->res_fail, 0, sizeof(int), e->stream));
       HIPCHK(hipMemsetAsync(e->c.st->res_dbg, 0, sizeof(int) * 4, e->stream));
     }
@@ -2804,7 +3078,7 @@ extern "C" int hipeng_reset_stats(hipeng *e) {
 extern "C" int hipeng_get_stats(hipeng *e, hipeng_stats *st) {
   if (!e || !st) return HIPENG_ERR_ARG;
   *st = e->stats;
-  st->resident = e->res_use ? 1 : 0;
+  st->resident = (e->res_on && e->res_fails < 3) ? 1 : 0;     // (a launch that gave up suspends the mode for the rest of that call only)
   return 0;
 }
 
@@ -2945,7 +3219,7 @@ extern "C" int hipeng_spmv_dev(hipeng *e, int which, const double *d_x, double *
 
 extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) {
   if (!e || !usec || reps <= 0 || which < 0 || which > 8) return HIPENG_ERR_ARG;
-  if (which == 8 && !e->res_use) return HIPENG_ERR_ARG;
+  if (which == 8 && !(e->res_on && e->res_fails < 3)) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   std::unique_lock<std::mutex> lease;
   if (which == 8) lease = std::unique_lock<std::mutex>(g_res_mu[e->device & 15]);
@@ -3002,21 +3276,23 @@ extern "C" int hipeng_is_split(hipeng *e) { return e && e->split ? 1 : 0; }
 
 // Resident PCG: out[0] structures built, [1] in use, [2] entries of K per thread, [3] workgroups, [4] nnz(K),
 // [5] LDS bytes per workgroup, [6] PCG iterations of the most recent linear solve, [7] pipelined phase switched off for this K,
-// [8] true-residual checks that failed since create
-extern "C" int hipeng_resident_info(hipeng *e, long long out[10]) {
+// [8] true-residual checks that failed since create, [9] form: 1 k_pcg_resident, 2 k_pcg_blockres,
+// [10] launches that gave up waiting (the third one ends the mode for this engine)
+extern "C" int hipeng_resident_info(hipeng *e, long long out[12]) {
   if (!e || !out) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   State s;
   if (read_state(e, &s)) return HIPENG_ERR_HIP;
-  out[0] = e->res_on; out[1] = e->res_use; out[2] = e->rc.E; out[3] = e->rc.nwg; out[4] = e->res_nnz; out[5] = (long long)e->res_lds;
-  out[6] = std::max(s.iters[0], s.iters[1]); out[7] = s.res_pipe_off; out[8] = s.res_chk_fail; out[9] = 0;
+  out[0] = e->res_on; out[1] = e->res_on && e->res_fails < 3; out[2] = e->rc.E; out[3] = e->rc.nwg; out[4] = e->res_nnz; out[5] = (long long)e->res_lds;
+  out[6] = std::max(s.iters[0], s.iters[1]); out[7] = s.res_pipe_off; out[8] = s.res_chk_fail; out[9] = e->res_kind; out[10] = e->res_fails; out[11] = 0;
+  if (e->res_kind == 2) { out[2] = 64; out[3] = e->bc.nwg; out[4] = 0; out[5] = 0; }
   return 0;
 }
 
 // Resident PCG, for the tests: the rows of K as the resident kernel holds them.  row/col/val receive nnz(K) triplets
 // (row by row, columns ascending; values read from the slots the threads load them from); returns the count or a negative code.
 extern "C" long long hipeng_resident_dump(hipeng *e, int *row, int *col, double *val, long long cap) {
-  if (!e || !e->res_on || !row || !col || !val) return HIPENG_ERR_ARG;
+  if (!e || e->res_kind != 1 || !row || !col || !val) return HIPENG_ERR_ARG;
   if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) return HIPENG_ERR_HIP;
   const ResCtx &rc = e->rc;
   const size_t slots = (size_t)rc.nwg * rc.E * RES_PT;

@@ -39,9 +39,9 @@ def _info(solver):
     L = osqp_amd.lib()
     L.hipeng_resident_info.restype = C.c_int
     L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
-    out = (C.c_longlong * 10)()
+    out = (C.c_longlong * 12)()
     assert L.hipeng_resident_info(solver.engine(), out) == 0
-    return dict(built=out[0], in_use=out[1], E=out[2], nwg=out[3], nnzK=out[4], lds=out[5], last_iters=out[6], pipe_off=out[7], checks_failed=out[8])
+    return dict(built=out[0], in_use=out[1], E=out[2], nwg=out[3], nnzK=out[4], lds=out[5], last_iters=out[6], pipe_off=out[7], checks_failed=out[8], form=out[9], gave_up=out[10])
 
 
 def _qp(n, m, seed, eq=0, dens=0.02):

@@ -17,6 +17,12 @@ for name in which:
     print("%s: setup %.2fs; %s in %d iters, %.3fs -> %.1f it/s; pcg/it %.1f; %.1f us per PCG iteration" % (
         name, ts, r.info.status, r.info.iter, tv, r.info.iter / tv, st["pcg_iters_total"] / r.info.iter, 1e6 * tv / st["pcg_iters_total"]))
     us = C.c_double(); L.hipeng_time_kernel(s.engine(), 5, 50, C.byref(us)); print("   k_pcg_init: %.1f us" % us.value)
+    if st.get("resident"):
+        L.hipeng_resident_info.restype = C.c_int; L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        info = (C.c_longlong * 12)(); up = C.c_double()
+        s.update_settings(max_iter=100); s.solve(); s.update_settings(max_iter=4000)      # a state in the middle of a solve
+        L.hipeng_time_kernel(s.engine(), 8, 50, C.byref(up)); L.hipeng_resident_info(s.engine(), info)
+        print("   resident launch (form %d): %.1f us for %d PCG iterations -> %.2f us each" % (info[9], up.value - us.value, info[6], (up.value - us.value) / max(1, info[6])))
     for k, nm in ((3, "k_cg_A update-only (split mode)"), (4, "k_cg_A apply-only (split mode)")):
         us = C.c_double(); L.hipeng_time_kernel(s.engine(), k, 100, C.byref(us)); print("   %s: %.1f us" % (nm, us.value))
     for k, nm in enumerate(("k_cg_A", "k_cg_B")):
