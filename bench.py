@@ -187,6 +187,23 @@ def other_configs(eps):
                          admm_iters_per_s=round(r.info.iter / tv, 1),
                          pcg_iters_per_admm_iter=round(st["pcg_iters_total"] / max(1, r.info.iter), 1),
                          usec_per_pcg_iter=round(1e6 * tv / max(1, st["pcg_iters_total"]), 1), pcg_kernels=rows)
+        if st.get("resident"):
+            # the linear solves of this config run as resident launches (config 5: k_pcg_blockres -- the dense blocks of P
+            # in registers, one exchange of four scalars per workgroup and PCG iteration); the kernels above are what the
+            # launch-per-step path (OSQP_AMD_RESIDENT=0) would use
+            L.hipeng_resident_info.restype = C.c_int
+            L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+            info = (C.c_longlong * 12)()
+            s.update_settings(max_iter=100); s.solve(); s.update_settings(max_iter=4000)     # a state in the middle of a solve
+            t_pair = C.c_double(); t_init = C.c_double()
+            if L.hipeng_time_kernel(s.engine(), 8, 50, C.byref(t_pair)) == 0:
+                L.hipeng_resident_info(s.engine(), info)
+                L.hipeng_time_kernel(s.engine(), 5, 50, C.byref(t_init))
+                us_l = t_pair.value - t_init.value
+                out[name]["pcg_kernels_note"] = "launch-per-step kernels, timed for reference; the solve above used resident launches"
+                out[name]["resident_launch"] = dict(form="k_pcg_blockres" if info[9] == 2 else "k_pcg_resident", usec=round(us_l, 1),
+                                                    pcg_iterations=int(info[6]), usec_per_pcg_iteration=round(us_l / max(1, int(info[6])), 2),
+                                                    bytes_read_once_per_launch_MB=round((s.nnzP * 2 - s.n) * 8 / 1e6, 1) if info[9] == 2 else None)
         if name.startswith("config3"):
             # BASELINE config 3 / SURVEY 8(d): the gamma sweep through osqp_update_lin_cost with warm-started re-solves
             # (docs/examples/lasso.rst:41-63), then perturbed data through osqp_update_A (same pattern) and a warm-started
