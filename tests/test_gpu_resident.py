@@ -111,7 +111,7 @@ def test_resident_modes_match_oracle(gpu_lib, oracle_mod, pipe):
         sg.update(q=q2); so.update(q=q2)
         rg, ro = sg.solve(), so.solve()
         assert rg.info.iter == ro.info.iter and _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
-        assert _info(sg)["in_use"]
+        assert _info(sg)["built"]
 
 
 def test_resident_hands_ill_conditioned_solves_to_the_robust_recurrences(gpu_lib, oracle_mod):
@@ -134,7 +134,7 @@ def test_resident_hands_ill_conditioned_solves_to_the_robust_recurrences(gpu_lib
     assert rg.info.status == ro.info.status == "solved"
     assert rg.info.iter == ro.info.iter
     assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-5
-    assert _info(sg)["in_use"]           # still resident: the hand-over happens inside the launch
+    assert _info(sg)["built"]            # still resident: the hand-over happens inside the launch
 
 
 def test_resident_on_tiny_problems(gpu_lib, oracle_mod):
@@ -164,6 +164,33 @@ def test_resident_with_many_entries_per_thread(gpu_lib, oracle_mod):
     assert rg.info.status == ro.info.status == "solved" and rg.info.iter == ro.info.iter
     assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
     assert _info(sg)["in_use"]
+
+
+def test_block_resident_portfolio_matches_oracle(gpu_lib, oracle_mod):
+    """k_pcg_blockres (P = dense diagonal blocks, rows of A single-entry + one huge budget row): 72 blocks of 125, the
+    budget row has 9000 entries.  Same trajectory as the oracle's direct solve; then new q and a warm-started solve; and the
+    same problem on the launch-per-step kernels (OSQP_AMD_RESIDENT_BLOCKS=0): one trajectory, two linear solvers."""
+    import osqp_amd
+    from osqp_amd.problems import portfolio_qp
+    pb = portfolio_qp(72, 125, seed=5)
+    kw = dict(eps_abs=1e-4, eps_rel=1e-4)
+    sg = osqp_amd.OSQP().setup(**pb, **kw); so = oracle_mod.OracleOSQP().setup(**pb, **kw)
+    inf = _info(sg)
+    assert inf["built"] and inf["form"] == 2, inf
+    rg, ro = sg.solve(), so.solve()
+    assert rg.info.status == ro.info.status == "solved"
+    assert rg.info.iter == ro.info.iter and rg.info.rho_updates == ro.info.rho_updates
+    assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
+    assert abs(rg.info.obj_val - ro.info.obj_val) <= 1e-6 * max(1.0, abs(ro.info.obj_val))     # (the bar of the full-size config-5 test)
+    q2 = pb["q"] * 0.9
+    sg.update(q=q2); so.update(q=q2)
+    rg2, ro2 = sg.solve(), so.solve()
+    assert rg2.info.iter == ro2.info.iter and _rel(rg2.x, ro2.x) < 1e-6 and _rel(rg2.y, ro2.y) < 1e-6
+    with _env(OSQP_AMD_RESIDENT_BLOCKS=0):
+        s2 = osqp_amd.OSQP().setup(**pb, **kw)
+    assert _info(s2)["form"] != 2
+    r2 = s2.solve()
+    assert r2.info.iter == rg.info.iter and _rel(r2.x, rg.x) < 1e-7 and _rel(r2.y, rg.y) < 1e-7
 
 
 def test_resident_off_by_environment_and_for_large_n(gpu_lib):
