@@ -972,6 +972,8 @@ struct ResCtx {
   const unsigned short *rowpos;      // position of row j in that vector
   int pipe;                          // 1: pipelined recurrences where they pass their checks (OSQP_AMD_RESIDENT_PIPE=0: never)
   int u0_direct;                     // 1: the first product reads u0 from global memory instead of exchanging it
+  int inject;                        // test hook (OSQP_AMD_RESIDENT_INJECT=k): in the launch of ADMM iteration k one workgroup walks away,
+                                     // the others' waits time out -- the give-up path on demand
   const ResWG *wg;
   double *val;                       // [nwg][E][RES_PT]: entry t*E + k of the workgroup's row-major list at (k, t)
   const unsigned short *col;         // same layout: POSITION of the entry's column in the exchanged vector
@@ -1072,6 +1074,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   const ResWG w = rc.wg[g];
   const Params prm = *c.prm;
   const unsigned ep0 = st->res_epoch;
+  const bool sabotage = rc.inject > 0 && g == 5 && st->admm_done + 1 == rc.inject;
   // pipelined recurrences only where a drift would be caught: not in the convexity probe, not after a failed check
   bool pipe = rc.pipe && !st->res_pipe_off && !prm.no_restart;
   // ---- own slice of K into registers (issued first: in flight under everything below) ----
@@ -1126,6 +1129,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   auto vec_exchange = [&](double val, bool ride) __attribute__((always_inline)) -> bool {
     double e0 = 0.0, e1 = 0.0, e2 = 0.0;     // riding partials of (r,u), (w,u), (r,r) when `ride`
     ++nx; tag = ep0 + (unsigned)nx; par = (int)(tag & 1u);
+    if (sabotage && nx == 3) return false;     // (test hook: this workgroup walks away without a word)
     RTL(0);
     const __amdgpu_buffer_rsrc_t rs = res_rsrc(rc.ubuf + (size_t)par * npad, (size_t)npad * 8);
     if (wv == 0) {
@@ -2403,6 +2407,8 @@ static int build_resident(hipeng *e) {
   rc.pipe = 1;
   if (const char *x = getenv("OSQP_AMD_RESIDENT_PIPE")) rc.pipe = atoi(x) != 0;
   rc.u0_direct = 1;
+  rc.inject = 0;
+  if (const char *x = getenv("OSQP_AMD_RESIDENT_INJECT")) rc.inject = atoi(x);
   if (const char *x = getenv("OSQP_AMD_RESIDENT_U0")) rc.u0_direct = atoi(x) != 0;
   unsigned short *d_rowpos = nullptr;
   ResWG *d_wg = nullptr; unsigned short *d_col = nullptr, *d_slot0 = nullptr, *d_segrow = nullptr; unsigned char *d_rowl = nullptr;
@@ -3027,6 +3033,11 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
       e->res_use = false;
       e->res_fails += 1;
       HIPCHK(hipMemsetAsync(&e->c.st->res_fail, 0, sizeof(int), e->stream));
+      // the launch that gave up left flags and granules with tags beyond the epoch it started from (it never wrote the
+      // epoch back): the next resident launch must not take them for its own -- start it far beyond (tags compare modulo 2^32)
+      e->h_state->res_epoch = s.res_epoch + (1u << 20);
+      HIPCHK(hipMemcpyAsync(&e->c.st->res_epoch, &e->h_state->res_epoch, sizeof(unsigned), hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
       HIPCHK(hipMemsetAsync(e->c.st->res_dbg, 0, sizeof(int) * 4, e->stream));
     }
     const long long done_now = s.admm_done - start;

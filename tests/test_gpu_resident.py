@@ -193,6 +193,30 @@ def test_block_resident_portfolio_matches_oracle(gpu_lib, oracle_mod):
     assert r2.info.iter == rg.info.iter and _rel(r2.x, rg.x) < 1e-7 and _rel(r2.y, rg.y) < 1e-7
 
 
+def test_a_launch_that_gives_up_costs_one_window(gpu_lib, oracle_mod):
+    """The give-up path on demand (OSQP_AMD_RESIDENT_INJECT: in the launch of ADMM iteration 40 one workgroup walks away).
+    That call finishes on the launch-per-step kernels, the next one is resident again -- with an epoch beyond the tags the
+    abandoned launch left in the exchange buffers -- and every result is the oracle's."""
+    import osqp_amd
+    pb = _qp(700, 500, 70, eq=60)
+    kw = dict(eps_abs=1e-5, eps_rel=1e-5, adaptive_rho_interval=25)
+    with _env(OSQP_AMD_RESIDENT_INJECT=40):
+        sg = osqp_amd.OSQP().setup(**pb, **kw)
+    so = oracle_mod.OracleOSQP().setup(**pb, **kw)
+    assert _info(sg)["in_use"] and _info(sg)["gave_up"] == 0
+    rg, ro = sg.solve(), so.solve()
+    assert rg.info.status == ro.info.status == "solved" and rg.info.iter == ro.info.iter > 40
+    assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
+    inf = _info(sg)
+    assert inf["gave_up"] == 1 and inf["in_use"] == 1, inf
+    for k in range(3):          # resident again: same trajectories as the oracle
+        q2 = pb["q"] * (1.0 + 0.1 * (k + 1))
+        sg.update(q=q2); so.update(q=q2)
+        rg, ro = sg.solve(), so.solve()
+        assert rg.info.iter == ro.info.iter and _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
+    assert _info(sg)["gave_up"] == 1
+
+
 def test_resident_off_by_environment_and_for_large_n(gpu_lib):
     import osqp_amd
     pb = _qp(400, 300, 50)
