@@ -959,7 +959,8 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
 #define RES_MAXN (RES_MAXROWS * 256)
 #define RES_MAXPAD 16384  // longest exchanged vector (doubles, lines padded)
 #define RES_MAXLD (RES_MAXPAD / 2 / RES_TB)   // 16-byte loads per thread that sweep the exchanged vector
-#define RES_WAIT_TICKS 2000000LL      // 20 ms of the 100 MHz wall clock per wait
+#define RES_WAIT_TICKS 2000000LL      // 20 ms of the 100 MHz wall clock for the waits of a launch's first real exchange (the grid may still
+                                      // be arriving); 1 ms for the later ones: by then every workgroup is known to be resident
 #define AUX_SC1 16
 #define RES_FSTRIDE 32   // 4-byte words between two workgroups' flags: a 128-byte line each
 #define RES_GSTRIDE 16   // doubles between two workgroups' granule slots: a 128-byte line each (no line is written by two CUs)
@@ -1163,7 +1164,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
         if (__all(ok)) break;
         ++rounds;
         if (rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }     // clock and give-up word only every 16th round
-        const bool late = wall_clock64() - t0 > RES_WAIT_TICKS;
+        const bool late = wall_clock64() - t0 > (nx > 2 ? RES_WAIT_TICKS / 20 : RES_WAIT_TICKS);
         if (late || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           if (late) {             // leave a note for the host's message: who waited for whom
             const unsigned long long miss = __ballot(!ok);
@@ -1271,7 +1272,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
         if (__all(pend == 0)) break;
         asm volatile("" ::: "memory");
         if (++rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }
-        const bool late = wall_clock64() - t0 > RES_WAIT_TICKS;
+        const bool late = wall_clock64() - t0 > (nx > 2 ? RES_WAIT_TICKS / 20 : RES_WAIT_TICKS);
         if (late || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           if (late) {
             const unsigned long long miss = __ballot(pend != 0);
@@ -1546,7 +1547,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
         if (__all(pend == 0)) break;
         asm volatile("" ::: "memory");
         if (++rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }
-        if (wall_clock64() - t0 > RES_WAIT_TICKS || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) tot[7] = 1.0; break; }
+        if (wall_clock64() - t0 > (nx > 2 ? RES_WAIT_TICKS / 20 : RES_WAIT_TICKS) || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) tot[7] = 1.0; break; }
         if ((rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __builtin_amdgcn_s_sleep(1);
       }
