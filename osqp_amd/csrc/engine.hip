@@ -2003,13 +2003,14 @@ static int dev_alloc(hipeng *e, T **p, size_t count) {
   return 0;
 }
 
-// Words that one CU polls while another writes them (exchange flags, tagged granules) live in fine-grained memory:
-// in ordinary device memory an XCD's L2 can keep an old copy of such a line for good (a whole XCD then polls the old
-// value while the others have moved on: seen about once in 1e5 exchanges, with every kind of load).
-// OSQP_AMD_RESIDENT_FINE=0 allocates them like everything else.
+// Words that one CU polls while another writes them (exchange flags, tagged granules) live in UNCACHED device memory
+// (hipDeviceMallocUncached): in ordinary memory an XCD's L2 can keep an old copy of such a line for good (a whole XCD
+// then polls the old value while the others have moved on: seen about once in 1e5 exchanges on small problems, with
+// every kind of load); uncached polls are also faster (143.6 against 149.8 us per ADMM iteration at config 2).
+// OSQP_AMD_RESIDENT_FINE=1: fine-grained (coherent) but cacheable; =0: like everything else.
 template <typename T>
 static int dev_alloc_polled(hipeng *e, T **p, size_t count) {
-  static const int fine = getenv("OSQP_AMD_RESIDENT_FINE") ? atoi(getenv("OSQP_AMD_RESIDENT_FINE")) : 1;
+  static const int fine = getenv("OSQP_AMD_RESIDENT_FINE") ? atoi(getenv("OSQP_AMD_RESIDENT_FINE")) : 2;
   if (!fine) return dev_alloc(e, p, count);
   void *q = nullptr;
   if (count == 0) count = 1;
