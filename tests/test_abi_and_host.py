@@ -223,3 +223,17 @@ def test_bench_spawns_before_touching_the_gpu():
     assert main.index("spawn_ranks(") < main.index("import torch") < main.index("import osqp_amd")
     head = src[:src.index("def parse():")]
     assert "import torch" not in head and "import osqp_amd" not in head
+
+
+def test_every_environment_variable_is_documented():
+    """Every OSQP_AMD_* variable the sources read appears in INTEGRATION.md (section F or the diagnostics paragraph)."""
+    import glob
+    names = set()
+    for pat in ("osqp_amd/csrc/*.c", "osqp_amd/csrc/*.hip", "osqp_amd/*.py"):
+        for f in glob.glob(os.path.join(ROOT, pat)):
+            txt = open(f, errors="ignore").read()
+            names |= set(re.findall(r'getenv\("(OSQP_AMD_[A-Z0-9_]+)"\)', txt))
+            names |= set(re.findall(r'environ\.get\("(OSQP_AMD_[A-Z0-9_]+)"', txt))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert len(names) > 20 and not missing, missing
