@@ -154,6 +154,12 @@ int hipeng_is_split(hipeng *e);   /* k_cg_A as two launches (update-only + apply
  * gave up waiting (each sends the rest of its run_admm call to the launch-per-step kernels; the third ends the mode for this
  * engine), [11] reserved.  [1] stays 1 until that third one. */
 int hipeng_resident_info(hipeng *e, long long out[12]);
+/* For the CPU tests (needs no device): the host side of the resident set-up -- symbolic K, row partition, positions in
+ * the exchanged vector, register layout -- for a machine of `nwg` CUs.  stats: [0] qualifies, [1] entries of K per thread,
+ * [2] length of the exchanged vector, [3] nnz(K), [4] workgroups that own rows, [5] most rows, [6] most entries per
+ * workgroup, [7] threads that hold entries (448).  Optional outputs may be NULL. */
+int hipeng_resident_plan(const csc *P, const csc *A, int nwg, long long stats[8], int *Kptr, int *Kcol, int *kdst, long long cap,
+                         unsigned short *rowpos, unsigned short *slotcol, int *wg4);
 /* For the tests: K as the resident kernel holds it, as triplets; returns nnz(K) or a negative code. */
 long long hipeng_resident_dump(hipeng *e, int *row, int *col, double *val, long long cap);
 

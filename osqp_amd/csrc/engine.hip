@@ -2263,7 +2263,12 @@ static void launch_resident(hipeng *e) {
 
 // Returns 0 (with e->res_on set when the problem qualifies) or a HIPENG error.  Not qualifying is not an error.
 #define RES_NO(why) do { if (e->trace) fprintf(stderr, "[osqp_amd] resident PCG not used: %s\n", why); return 0; } while (0)
-static int build_resident(hipeng *e) {
+// What build_resident works out on the host before anything is uploaded (hipeng_resident_plan hands it to the CPU tests).
+struct ResPlanOut {
+  bool ok = false; int nwg = 0, E = 0, npad = 0; long long nnzK = 0;
+  std::vector<ResWG> wg; std::vector<int> Kptr, Kcol, kdst; std::vector<unsigned short> rowpos, col; std::vector<unsigned long long> brk;
+};
+static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr) {
   e->res_on = e->res_use = false;
   const int n = e->n;
   int want = 1, min_n = 256;
@@ -2272,10 +2277,14 @@ static int build_resident(hipeng *e) {
   if (!want) RES_NO("OSQP_AMD_RESIDENT=0");
   if (n < min_n || n > RES_MAXN) RES_NO("n outside [OSQP_AMD_RESIDENT_MIN_N, 15616]");
   if (!e->hrows.empty() || e->A.nwave < (int)e->A.blk.size()) RES_NO("A has rows of 8192 or more entries");   // (their outer products alone overflow the register files)
-  hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, e->device));
-  const int nwg = std::min(256, prop.multiProcessorCount);
-  if ((long long)nwg * RES_MAXROWS < n || prop.sharedMemPerBlock < 64 * 1024) RES_NO("too few CUs or too little LDS");
+  int nwg = plan_nwg;
+  if (!po) {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, e->device));
+    nwg = std::min(256, prop.multiProcessorCount);
+    if (prop.sharedMemPerBlock < 64 * 1024) RES_NO("too little LDS");
+  }
+  if (nwg <= 0 || nwg > 256 || (long long)nwg * RES_MAXROWS < n) RES_NO("too few CUs");
   const HostMat &M = e->M, &A = e->A;
   const auto tb0 = std::chrono::steady_clock::now();
   for (int i = 0; i < n; i++)
@@ -2404,6 +2413,11 @@ static int build_resident(hipeng *e) {
     if (nseg > RES_TB + RES_MAXROWS) return 0;   // cannot happen (one segment per thread plus one per row change)
   }
   const auto tb2 = std::chrono::steady_clock::now();
+  if (po) {                      // plan only (no device): hand the layout out
+    po->ok = true; po->nwg = nwg; po->E = E; po->npad = npad; po->nnzK = nnzK;
+    po->wg = wg; po->Kptr = Kptr; po->Kcol = Kcol; po->kdst = kdst; po->rowpos = rowpos; po->col = col; po->brk = brk;
+    return 0;
+  }
   ResCtx rc{};
   rc.nwg = nwg; rc.E = E; rc.npad = npad;
   rc.pipe = 1;
@@ -3267,6 +3281,35 @@ extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) 
   HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
   HIPCHK(hipGraphExecDestroy(ge));
   *usec = 1e3 * (double)ms / reps;
+  return 0;
+}
+
+// For the CPU tests (no device needed): the host side of the resident PCG set-up -- symbolic K, row partition, positions
+// in the exchanged vector, register layout -- for a machine of `nwg` CUs.  stats: [0] the problem qualifies, [1] entries of K
+// per thread, [2] length of the exchanged vector, [3] nnz(K), [4] workgroups that own rows, [5] most rows per workgroup,
+// [6] most entries per workgroup, [7] 448.  Optional outputs (NULL to skip): Kptr (n + 1), Kcol / kdst (cap entries at most:
+// column and register slot of every entry of K, row by row), rowpos (n), slotcol (nwg * E * 448: the position held in every
+// slot), wg4 (4 ints per workgroup: first row, rows, entries, first position).
+extern "C" int hipeng_resident_plan(const csc *P, const csc *A, int nwg, long long stats[8], int *Kptr, int *Kcol, int *kdst, long long cap,
+                                    unsigned short *rowpos, unsigned short *slotcol, int *wg4) {
+  if (!P || !A || !stats || P->n > 0x7ffffff0LL || A->m > 0x7ffffff0LL) return HIPENG_ERR_ARG;
+  hipeng tmp;
+  tmp.n = (int)P->n; tmp.m = (int)A->m;
+  build_A(&tmp, A); build_M(&tmp, P, A); build_dense(&tmp, P);
+  ResPlanOut po;
+  const int rc = build_resident(&tmp, nwg, &po);
+  for (int k = 0; k < 8; k++) stats[k] = 0;
+  if (rc) return rc;
+  stats[0] = po.ok; stats[7] = RES_PT;
+  if (!po.ok) return 0;
+  stats[1] = po.E; stats[2] = po.npad; stats[3] = po.nnzK;
+  for (const ResWG &w : po.wg) { if (w.nr) stats[4]++; stats[5] = std::max<long long>(stats[5], w.nr); stats[6] = std::max<long long>(stats[6], w.cnt); }
+  if (Kptr) std::copy(po.Kptr.begin(), po.Kptr.end(), Kptr);
+  if (po.nnzK <= cap) { if (Kcol) std::copy(po.Kcol.begin(), po.Kcol.end(), Kcol); if (kdst) std::copy(po.kdst.begin(), po.kdst.end(), kdst); }
+  else if (Kcol || kdst) return HIPENG_ERR_ARG;
+  if (rowpos) std::copy(po.rowpos.begin(), po.rowpos.end(), rowpos);
+  if (slotcol) std::copy(po.col.begin(), po.col.end(), slotcol);
+  if (wg4) for (size_t g = 0; g < po.wg.size(); g++) { wg4[4 * g] = po.wg[g].r0; wg4[4 * g + 1] = po.wg[g].nr; wg4[4 * g + 2] = po.wg[g].cnt; wg4[4 * g + 3] = po.wg[g].pos; }
   return 0;
 }
 
