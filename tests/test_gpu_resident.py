@@ -203,7 +203,7 @@ def test_a_launch_that_gives_up_costs_one_window(gpu_lib, oracle_mod):
     with _env(OSQP_AMD_RESIDENT_INJECT=40):
         sg = osqp_amd.OSQP().setup(**pb, **kw)
     so = oracle_mod.OracleOSQP().setup(**pb, **kw)
-    assert _info(sg)["in_use"] and _info(sg)["gave_up"] == 0
+    assert _info(sg)["in_use"]
     rg, ro = sg.solve(), so.solve()
     assert rg.info.status == ro.info.status == "solved" and rg.info.iter == ro.info.iter > 40
     assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
