@@ -93,7 +93,10 @@ def kernel_roofline(solver, reps=300):
         solver.solve()
         solver.update_settings(max_iter=4000)
         t_pair = C.c_double(); t_init = C.c_double()
-        assert L.hipeng_time_kernel(solver.engine(), 8, reps2, C.byref(t_pair)) == 0
+        ok8 = L.hipeng_time_kernel(solver.engine(), 8, reps2, C.byref(t_pair)) == 0
+        if not ok8:                               # a launch of the timed run gave up (rare): once more
+            ok8 = L.hipeng_time_kernel(solver.engine(), 8, reps2, C.byref(t_pair)) == 0
+        assert ok8
         assert L.hipeng_resident_info(solver.engine(), info) == 0
         its = int(info[6])                       # (k_pcg_init resets the count: read it before timing that kernel alone)
         assert L.hipeng_time_kernel(solver.engine(), 5, reps2, C.byref(t_init)) == 0
