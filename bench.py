@@ -78,7 +78,7 @@ def kernel_roofline(solver, reps=300):
                                        note="one PCG iteration = k_cg_A + k_cg_B in loop order; bytes = SURVEY 8(d) B_pcg"))
     L.hipeng_resident_info.restype = C.c_int
     L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
-    info = (C.c_longlong * 12)()
+    info = (C.c_longlong * 16)()
     assert L.hipeng_resident_info(solver.engine(), info) == 0
     if info[1]:
         # Resident engine: ONE launch of k_pcg_resident is the whole linear solve of an ADMM iteration (K in registers,
@@ -93,10 +93,7 @@ def kernel_roofline(solver, reps=300):
         solver.solve()
         solver.update_settings(max_iter=4000)
         t_pair = C.c_double(); t_init = C.c_double()
-        ok8 = L.hipeng_time_kernel(solver.engine(), 8, reps2, C.byref(t_pair)) == 0
-        if not ok8:                               # a launch of the timed run gave up (rare): once more
-            ok8 = L.hipeng_time_kernel(solver.engine(), 8, reps2, C.byref(t_pair)) == 0
-        assert ok8
+        assert L.hipeng_time_kernel(solver.engine(), 8, reps2, C.byref(t_pair)) == 0, "a resident launch of the timed run gave up"
         assert L.hipeng_resident_info(solver.engine(), info) == 0
         its = int(info[6])                       # (k_pcg_init resets the count: read it before timing that kernel alone)
         assert L.hipeng_time_kernel(solver.engine(), 5, reps2, C.byref(t_init)) == 0
@@ -117,6 +114,7 @@ def kernel_roofline(solver, reps=300):
                     bytes_per_launch=b_pcg * its, usec_per_launch=round(us, 3), pcg_iterations_per_launch=its,
                     usec_per_pcg_iteration=round(us / max(its, 1), 3),
                     resident=dict(nnzK=int(info[4]), workgroups=int(info[3]), entries_per_thread=int(info[2]), lds_bytes=int(info[5]),
+                                  gave_up=int(info[10]), slow_waits=int(info[11]), slow_wait_max_us=round(int(info[12]) * 0.01, 1), republished=int(info[13]),
                                   register_bytes_of_K=int(info[4]) * 10,
                                   # what the launch moves on chip instead of streaming matrices: every CU reads the exchanged vector
                                   # (rows + riding partials, line-padded) once per PCG iteration
@@ -196,7 +194,7 @@ def other_configs(eps):
             # launch-per-step path (OSQP_AMD_RESIDENT=0) would use
             L.hipeng_resident_info.restype = C.c_int
             L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
-            info = (C.c_longlong * 12)()
+            info = (C.c_longlong * 16)()
             s.update_settings(max_iter=100); s.solve(); s.update_settings(max_iter=4000)     # a state in the middle of a solve
             t_pair = C.c_double(); t_init = C.c_double()
             if L.hipeng_time_kernel(s.engine(), 8, 50, C.byref(t_pair)) == 0:

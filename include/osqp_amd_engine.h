@@ -151,11 +151,14 @@ int hipeng_is_split(hipeng *e);   /* k_cg_A as two launches (update-only + apply
  * [3] workgroups, [4] nnz(K), [5] LDS bytes per workgroup, [6] PCG iterations of the most recent linear
  * solve, [7] pipelined recurrences switched off for the current K, [8] true-residual checks that failed since create
  * (each continued its solve from the true residual), [9] form (1: k_pcg_resident, 2: k_pcg_blockres), [10] launches that
- * gave up waiting (each sends the rest of its run_admm call to the launch-per-step kernels; the third ends the mode for this
- * engine), [11] reserved.  [1] stays 1 until that third one. */
-int hipeng_resident_info(hipeng *e, long long out[12]);
+ * gave up waiting since create (each sends the rest of its run_admm call to the launch-per-step kernels), [11] waits inside
+ * resident launches that ended well but took more than 50 us, [12] the longest of them in ticks of the 100 MHz clock,
+ * [13] flags / granules stored again by a workgroup whose own wait went on, [14] give-ups in a row (the third ends the mode
+ * for this engine; a run_admm call without one starts the count again), [15] reserved.  [1] stays 1 until that third one. */
+int hipeng_resident_info(hipeng *e, long long out[16]);
 /* For the CPU tests (needs no device): the host side of the resident set-up -- symbolic K, row partition, positions in
- * the exchanged vector, register layout -- for a machine of `nwg` CUs.  stats: [0] qualifies, [1] entries of K per thread,
+ * the exchanged vector, register layout -- for a grid of exactly `nwg` workgroups (nwg > 0) or, nwg < 0, with the grid sized
+ * to the problem as the engine does on a machine of -nwg CUs (stats[4] then tells the grid).  stats: [0] qualifies, [1] entries of K per thread,
  * [2] length of the exchanged vector, [3] nnz(K), [4] workgroups that own rows, [5] most rows, [6] most entries per
  * workgroup, [7] threads that hold entries (448).  Optional outputs may be NULL. */
 int hipeng_resident_plan(const csc *P, const csc *A, int nwg, long long stats[8], int *Kptr, int *Kcol, int *kdst, long long cap,

@@ -114,6 +114,9 @@ struct State {
   int    res_pipe_off;     // resident PCG: the pipelined recurrences failed a true-residual check for this K (k_form_K clears it)
   int    res_chk_fail;     // resident PCG: true-residual checks that failed since create (each continued the solve from the true residual)
   int    res_dbg[4];       // resident PCG, first timed-out wait: 1 = flags / 2 = granules, exchange number, waiting workgroup, first missing workgroup
+  int    res_slow;         // resident PCG: waits that ended well but took more than 50 us (the host adds them up: hipeng_resident_info)
+  int    res_slow_max;     // ... the longest of them, in ticks of the 100 MHz clock
+  int    res_repub;        // ... flags / granules that a workgroup stored again because its own wait went on (every 64th round)
 };
 
 struct Params {          // mutable scalars (host writes, kernels read)
@@ -959,9 +962,13 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
 #define RES_MAXN (RES_MAXROWS * 256)
 #define RES_MAXPAD 16384  // longest exchanged vector (doubles, lines padded)
 #define RES_MAXLD (RES_MAXPAD / 2 / RES_TB)   // 16-byte loads per thread that sweep the exchanged vector
-#define RES_WAIT_TICKS 2000000LL      // 20 ms of the 100 MHz wall clock for the waits of a launch's first real exchange (the grid may still
-                                      // be arriving); 1 ms for the later ones: by then every workgroup is known to be resident
+#define RES_WAIT_TICKS 2000000LL      // 20 ms of the 100 MHz wall clock: the limit of every wait inside a resident launch (the grid may still be
+                                      // arriving in the first one; a later one that long means a workgroup is gone).  Two readings 16 rounds apart
+                                      // must both say so, and a reading that cannot be (negative, or hours) restarts the wait's clock.
+#define RES_SLOW_TICKS 5000LL         // a wait that ended well after more than 50 us is counted (State::res_slow)
 #define AUX_SC1 16
+#define AUX_VOL ((int)0x80000000)     // volatile: a poll load the compiler must neither hoist out of its loop nor merge
+#define RES_DBG 16                    // ints per workgroup in ResCtx::dbg
 #define RES_FSTRIDE 32   // 4-byte words between two workgroups' flags: a 128-byte line each
 #define RES_GSTRIDE 16   // doubles between two workgroups' granule slots: a 128-byte line each (no line is written by two CUs)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -970,6 +977,7 @@ struct ResWG { int r0, nr, cnt, pos; };   // first row, rows (<= RES_MAXROWS), e
 struct ResCtx {
   int nwg, E, npad;                  // workgroups, entries per thread, length of the exchanged vector: every workgroup's rows + its three
                                      // dot partials, padded to whole 128-byte lines (a line written by two CUs can lose one of the writes)
+  int npw;                           // wavefronts of each workgroup that poll: ceil(nwg / 64), one flag (or one workgroup's granules) per lane
   const unsigned short *rowpos;      // position of row j in that vector
   int pipe;                          // 1: pipelined recurrences where they pass their checks (OSQP_AMD_RESIDENT_PIPE=0: never)
   int u0_direct;                     // 1: the first product reads u0 from global memory instead of exchanging it
@@ -985,12 +993,45 @@ struct ResCtx {
   const unsigned short *segrow;      // [nwg][RES_MAXROWS + 1]: first segment slot of each local row
   double *ubuf;                      // 2 x npad doubles (parity of the tag)
   unsigned *flags;                   // nwg x RES_FSTRIDE words (one 128-byte line each)
-  int *dbg;                          // nwg x 4: exchange number, mode, PCG iterations, 1 + kind of the wait that timed out (0: left because another did)
+  int *dbg;                          // nwg x RES_DBG, written by a launch that gives up: see res_note()
   double *sbuf;                      // 2 x nwg x RES_GSTRIDE 8-byte words: six granules {32 bits of a double, tag} per workgroup, one line each
 };
 
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const void *p, size_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+// ---- waits inside a resident launch (k_pcg_resident, k_pcg_blockres) ----
+// Every wait is a bounded spin of ceil(nwg / 64) wavefronts, one polled workgroup per lane, re-loading only what is still
+// missing.  Every 16th round the wave looks at the clock and at the give-up word; every 64th the workgroup stores its own
+// flag / granules again (idempotent: should a store ever go missing, the others do not hang on it) -- counted in
+// State::res_repub; a wait that ends well after more than 50 us is counted in State::res_slow.
+// res_spin_check: 0 = keep polling, 1 = this wait has timed out, 2 = another workgroup gave up.
+__device__ __forceinline__ int res_spin_check(State *st, long long &t0, int &late) {
+  const long long now = wall_clock64();
+  const long long el = now - t0;
+  if (el < 0 || el > (1LL << 40)) { t0 = now; late = 0; return 0; }      // not a time: start this wait's clock again
+  if (__hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 2;
+  if (el > RES_WAIT_TICKS) { if (late) return 1; late = 1; } else late = 0;
+  return 0;
+}
+// What a workgroup leaves for the host when it gives up (ResCtx::dbg, RES_DBG ints per workgroup):
+//   [0] exchange number  [1] mode  [2] PCG iterations          (written at the kernel's exit)
+//   [3] 1 / 2: its flag / granule wait timed out, 3: it left because another workgroup had given up
+//   [4] first workgroup it still missed (-1: none)   [5] the word it last read from that workgroup (flag, or a granule's tag)
+//   [6] ticks it had waited (100 MHz)   [7] XCC id   [8] clock at the give-up (low 32 bits)   [9] rounds   [10] granule index
+// Publishing time of a workgroup's last flag = [8] - [6]: its wait started right behind its own store.
+__device__ __forceinline__ void res_note(State *st, int *dbg, int g, int verdict, int kind, int nx, int first, unsigned seen, long long t0, unsigned rounds, int gidx) {
+  if (verdict == 1 && atomicCAS(&st->res_dbg[0], 0, kind) == 0) { st->res_dbg[1] = nx; st->res_dbg[2] = g; st->res_dbg[3] = first; }
+  int *d = dbg + (size_t)RES_DBG * g;
+  const long long now = wall_clock64();
+  d[3] = verdict == 1 ? kind : 3; d[4] = first; d[5] = (int)seen; d[6] = (int)(now - t0);
+  d[7] = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20);        // HW_REG_XCC_ID, bits 3:0
+  d[8] = (int)(unsigned)now; d[9] = (int)rounds; d[10] = gidx;
+}
+__device__ __forceinline__ void res_slow_note(State *st, long long t0) {
+  const long long el = wall_clock64() - t0;
+  if (el > RES_SLOW_TICKS && el < (1LL << 40)) { atomicAdd(&st->res_slow, 1); atomicMax(&st->res_slow_max, (int)(el > 0x7fffffffLL ? 0x7fffffffLL : el)); }
 }
 
 // K values in the resident layout.  K_ij = P_ij + sigma [i == j] + sum_k rho_k (A_ki A_kj): the sum runs over the rows k
@@ -1075,7 +1116,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   const ResWG w = rc.wg[g];
   const Params prm = *c.prm;
   const unsigned ep0 = st->res_epoch;
-  const bool sabotage = rc.inject > 0 && g == 5 && st->admm_done + 1 == rc.inject;
+  const bool sabotage = rc.inject > 0 && g == rc.nwg - 1 && st->admm_done + 1 == rc.inject;
   // pipelined recurrences only where a drift would be caught: not in the convexity probe, not after a failed check
   bool pipe = rc.pipe && !st->res_pipe_off && !prm.no_restart;
   // ---- own slice of K into registers (issued first: in flight under everything below) ----
@@ -1149,33 +1190,39 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(rc.flags + (size_t)g * RES_FSTRIDE, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (wv < 4) {
-      // wavefronts 0..3 poll the 256 flags, ONE flag per lane: a lane that polled four flags waited for each load
-      // before it issued the next (the compiler keeps atomic loads in order), four round trips per look
+    if (wv < rc.npw) {
+      // ceil(nwg / 64) wavefronts poll, ONE flag per lane (a lane that polled four flags with atomic loads waited for each
+      // before it issued the next), and only until that flag has been seen; the own flag is not polled
       const int o = t;                         // flag of workgroup t
-      const long long t0 = wall_clock64();
-      unsigned rounds = 0;
+      bool pend = o < nwg && o != g;
+      unsigned seen = 0, rounds = 0;
+      long long t0 = wall_clock64();
+      int late = 0;
+      bool gave = false;
       while (true) {
-        bool ok = true;
-        if (o < nwg) {
-          const unsigned f = __hip_atomic_load(rc.flags + (size_t)o * RES_FSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = (int)(f - tag) >= 0;
+        if (pend) {
+          seen = __hip_atomic_load(rc.flags + (size_t)o * RES_FSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pend = (int)(seen - tag) < 0;
         }
-        if (__all(ok)) break;
-        ++rounds;
-        if (rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }     // clock and give-up word only every 16th round
-        const bool late = wall_clock64() - t0 > (nx > 2 ? RES_WAIT_TICKS / 20 : RES_WAIT_TICKS);
-        if (late || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-          if (late) {             // leave a note for the host's message: who waited for whom
-            const unsigned long long miss = __ballot(!ok);
-            if (lane == 0 && atomicCAS(&st->res_dbg[0], 0, 1) == 0) { st->res_dbg[1] = nx; st->res_dbg[2] = g; st->res_dbg[3] = miss ? 64 * wv + (int)__ffsll((long long)miss) - 1 : -1; }
-          }
-          if (lane == 0) sc[3] = 1.0;
+        if (!__any(pend)) break;
+        if (++rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }     // clock and give-up word only every 16th round
+        const int verdict = res_spin_check(st, t0, late);
+        if (verdict) {
+          const unsigned long long miss = __ballot(pend);
+          const int fl = miss ? (int)__ffsll((long long)miss) - 1 : 0;
+          const unsigned sv = (unsigned)__builtin_amdgcn_readlane((int)seen, fl);
+          if (lane == 0) { res_note(st, rc.dbg, g, verdict, 1, nx, miss ? 64 * wv + fl : -1, sv, t0, rounds, 0); sc[3] = 1.0; }
+          gave = true;
           break;
+        }
+        if ((rounds & 63u) == 0 && wv == 0 && lane == 0) {       // a long wait: say it again
+          __hip_atomic_store(rc.flags + (size_t)g * RES_FSTRIDE, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicAdd(&st->res_repub, 1);
         }
         if ((rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __builtin_amdgcn_s_sleep(1);
       }
+      if (rounds >= 16u && lane == 0 && !gave) res_slow_note(st, t0);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __syncthreads();
@@ -1240,9 +1287,8 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   };
   // Exchange (2): three dot partials per workgroup as tagged granules (the data is the flag); totals in sc[0..2].
   auto scal_exchange = [&](double pg, double pd, double prr) __attribute__((always_inline)) -> bool {
-    // granules of 8 bytes {32 bits of data, tag}: six per workgroup, in a line of the workgroup's own; stored and read
-    // with agent-scope atomic accesses; ONE workgroup's six per thread of wavefronts 0..3 (the compiler keeps atomic
-    // loads in order: when one wavefront swept everything a look took 24 round trips)
+    // granules of 8 bytes {32 bits of data, tag}: six per workgroup, in a line of the workgroup's own, stored with
+    // agent-scope atomic stores
     unsigned long long *gb = reinterpret_cast<unsigned long long *>(rc.sbuf) + (size_t)par * nwg * RES_GSTRIDE;
     if (wv == 0) {
       pg = wave_sum(pg); pd = wave_sum(pd); prr = wave_sum(prr);
@@ -1252,43 +1298,51 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
         __hip_atomic_store(gb + (size_t)g * RES_GSTRIDE + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (wv < 4) {
+    if (wv < rc.npw) {
+      // ceil(nwg / 64) wavefronts poll, ONE workgroup's six granules per lane, all six loads in flight together
+      // (buffer_load_dwordx2 sc1, volatile; six atomic loads went one after the other: 1.9-2.2 us per exchange against
+      // 1.5-1.75 at up to 64 workgroups, tools/exchange_probe2.hip), and only the granules still missing.  Each granule vouches
+      // for itself; a half arrives in LDS as soon as its tag matches.
       const int o = t;                         // the workgroup whose granules this thread fetches
+      const __amdgpu_buffer_rsrc_t rg = res_rsrc(gb, (size_t)nwg * RES_GSTRIDE * 8);
       unsigned pend = o < nwg ? 63u : 0u;
-      unsigned gv[6];
-      const long long t0 = wall_clock64();
-      unsigned rounds = 0;
+      unsigned *svw = reinterpret_cast<unsigned *>(sval) + 6 * o;
+      unsigned seen = 0, rounds = 0;
+      long long t0 = wall_clock64();
+      int late = 0;
+      bool gave = false;
       while (true) {
-        // (agent-scope atomic loads, global_load_dwordx2 sc1, one after the other: sweeps with buffer_load_dwordx2/x4 sc1 --
-        // several loads of one line in flight while its write arrives -- left, once in ~1e5 exchanges, a few workgroups of
-        // ONE XCD reading the old line for good while the other 249 had moved on; reading with atomic OR / compare-and-swap
-        // once a poll looks stuck is worse: those write, and lost the owner's store now and then)
+        u32x2 gv[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) if (pend & (1u << q)) gv[q] = __builtin_amdgcn_raw_buffer_load_b64(rg, (o * RES_GSTRIDE + q) * 8, 0, AUX_SC1 | AUX_VOL);
 #pragma unroll
         for (int q = 0; q < 6; ++q)
-          if (pend & (1u << q)) {
-            const unsigned long long v = __hip_atomic_load(gb + (size_t)o * RES_GSTRIDE + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(v >> 32) == tag) { gv[q] = (unsigned)v; pend &= ~(1u << q); }
-          }
-        if (__all(pend == 0)) break;
+          if (pend & (1u << q)) { if (gv[q].y == tag) { svw[q] = gv[q].x; pend &= ~(1u << q); } else seen = gv[q].y; }
+        if (!__any(pend != 0)) break;
         asm volatile("" ::: "memory");
         if (++rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }
-        const bool late = wall_clock64() - t0 > (nx > 2 ? RES_WAIT_TICKS / 20 : RES_WAIT_TICKS);
-        if (late || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-          if (late) {
-            const unsigned long long miss = __ballot(pend != 0);
-            if (lane == 0 && atomicCAS(&st->res_dbg[0], 0, 2) == 0) { st->res_dbg[1] = nx; st->res_dbg[2] = g; st->res_dbg[3] = miss ? 64 * wv + (int)__ffsll((long long)miss) - 1 : -1; }
-          }
-          if (lane == 0) sc[3] = 1.0;
+        const int verdict = res_spin_check(st, t0, late);
+        if (verdict) {
+          const unsigned long long miss = __ballot(pend != 0);
+          const int fl = miss ? (int)__ffsll((long long)miss) - 1 : 0;
+          const unsigned sv = (unsigned)__builtin_amdgcn_readlane((int)seen, fl);
+          const int gi = __builtin_amdgcn_readlane((int)pend, fl);
+          if (lane == 0) { res_note(st, rc.dbg, g, verdict, 2, nx, miss ? 64 * wv + fl : -1, sv, t0, rounds, gi); sc[3] = 1.0; }
+          gave = true;
           break;
+        }
+        if ((rounds & 63u) == 0 && wv == 0) {          // a long wait: say it again
+          if (lane < 6) {
+            const double v = lane < 2 ? pg : (lane < 4 ? pd : prr);
+            const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+            __hip_atomic_store(gb + (size_t)g * RES_GSTRIDE + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (lane == 0) atomicAdd(&st->res_repub, 1);
         }
         if ((rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // a poll that stays unanswered this long: drop whatever this CU still caches
         __builtin_amdgcn_s_sleep(1);
       }
-      if (o < nwg) {
-        sval[3 * o] = __hiloint2double((int)gv[1], (int)gv[0]);
-        sval[3 * o + 1] = __hiloint2double((int)gv[3], (int)gv[2]);
-        sval[3 * o + 2] = __hiloint2double((int)gv[5], (int)gv[4]);
-      }
+      if (rounds >= 16u && lane == 0 && !gave) res_slow_note(st, t0);
     }
     __syncthreads();
     if (wv == 0) {
@@ -1397,7 +1451,9 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   if (failed) {
     if (t == 0) {
       __hip_atomic_store(&st->res_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      rc.dbg[4 * g] = nx; rc.dbg[4 * g + 1] = mode; rc.dbg[4 * g + 2] = iters; rc.dbg[4 * g + 3] = 1;
+      int *d = rc.dbg + (size_t)RES_DBG * g;
+      d[0] = nx; d[1] = mode; d[2] = iters;
+      if (sabotage) { d[3] = 4; d[7] = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20); d[8] = (int)(unsigned)wall_clock64(); }
     }
     return;
   }
@@ -1439,7 +1495,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
 // everything else is local.  Chronopoulos-Gear recurrences with a fresh product (cg_step), 3 barriers per iteration.
 // The 50 MB of blocks are read once per launch instead of once per PCG iteration.
 // ---------------------------------------------------------------------------
-struct BrCtx { int nwg; const int *blk0; double *sbuf; };
+struct BrCtx { int nwg; const int *blk0; double *sbuf; int *dbg; };
 
 template <int NH>
 __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
@@ -1530,31 +1586,51 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
       const unsigned half = (lane & 1) ? (unsigned)__double2hiint(sv) : (unsigned)__double2loint(sv);
       __hip_atomic_store(gb + (size_t)g * RES_GSTRIDE + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (wv < 4) {
-      // one workgroup's 2 NV granules per thread of wavefronts 0..3
+    if (wv < ((nwg + 63) >> 6)) {
+      // one workgroup's 2 NV granules per lane, all loads in flight together, only what is still missing (see k_pcg_resident)
       const int o = t;
+      const __amdgpu_buffer_rsrc_t rg = res_rsrc(gb, (size_t)nwg * RES_GSTRIDE * 8);
       unsigned pend = o < nwg ? (1u << (2 * NV)) - 1u : 0u;
-      unsigned gv[2 * NV];
-      const long long t0 = wall_clock64();
-      unsigned rounds = 0;
+      unsigned *svw = reinterpret_cast<unsigned *>(sval) + 2 * NV * o;
+      unsigned seen = 0, rounds = 0;
+      long long t0 = wall_clock64();
+      int late = 0;
+      bool gave = false;
       while (true) {
+        u32x2 gv[2 * NV];
 #pragma unroll
-        for (int q = 0; q < 2 * NV; ++q)          // agent-scope atomic loads (see k_pcg_resident on why not buffer loads)
-          if (pend & (1u << q)) {
-            const unsigned long long v = __hip_atomic_load(gb + (size_t)o * RES_GSTRIDE + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(v >> 32) == tag) { gv[q] = (unsigned)v; pend &= ~(1u << q); }
-          }
-        if (__all(pend == 0)) break;
+        for (int q = 0; q < 2 * NV; ++q) if (pend & (1u << q)) gv[q] = __builtin_amdgcn_raw_buffer_load_b64(rg, (o * RES_GSTRIDE + q) * 8, 0, AUX_SC1 | AUX_VOL);
+#pragma unroll
+        for (int q = 0; q < 2 * NV; ++q)
+          if (pend & (1u << q)) { if (gv[q].y == tag) { svw[q] = gv[q].x; pend &= ~(1u << q); } else seen = gv[q].y; }
+        if (!__any(pend != 0)) break;
         asm volatile("" ::: "memory");
         if (++rounds & 15u) { __builtin_amdgcn_s_sleep(1); continue; }
-        if (wall_clock64() - t0 > (nx > 2 ? RES_WAIT_TICKS / 20 : RES_WAIT_TICKS) || __hip_atomic_load(&st->res_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) tot[7] = 1.0; break; }
+        const int verdict = res_spin_check(st, t0, late);
+        if (verdict) {
+          const unsigned long long miss = __ballot(pend != 0);
+          const int fl = miss ? (int)__ffsll((long long)miss) - 1 : 0;
+          const unsigned sv = (unsigned)__builtin_amdgcn_readlane((int)seen, fl);
+          const int gi = __builtin_amdgcn_readlane((int)pend, fl);
+          if (lane == 0) { res_note(st, bc.dbg, g, verdict, 2, nx, miss ? 64 * wv + fl : -1, sv, t0, rounds, gi); tot[7] = 1.0; }
+          gave = true;
+          break;
+        }
+        if ((rounds & 63u) == 0 && wv == 0) {          // a long wait: say it again
+          if (lane < 2 * NV) {
+            const int i = lane >> 1;
+            double sv2 = 0.0;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) sv2 += red[w8 * 8 + i];
+            const unsigned half = (lane & 1) ? (unsigned)__double2hiint(sv2) : (unsigned)__double2loint(sv2);
+            __hip_atomic_store(gb + (size_t)g * RES_GSTRIDE + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (lane == 0) atomicAdd(&st->res_repub, 1);
+        }
         if ((rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __builtin_amdgcn_s_sleep(1);
       }
-      if (o < nwg) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) sval[NV * o + i] = __hiloint2double((int)gv[2 * i + 1], (int)gv[2 * i]);
-      }
+      if (rounds >= 16u && lane == 0 && !gave) res_slow_note(st, t0);
     }
     __syncthreads();
     if (wv == 0) {
@@ -1588,7 +1664,11 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
     }
   }
   if (failed) {
-    if (t == 0) __hip_atomic_store(&st->res_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) {
+      __hip_atomic_store(&st->res_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int *d = bc.dbg + (size_t)RES_DBG * g;
+      d[0] = nx; d[1] = 3; d[2] = iters;
+    }
     return;
   }
   if (own && iters > 0) c.va[j] = x_;
@@ -1983,8 +2063,10 @@ struct hipeng {
   long long admm_done_seen = 0;
   bool res_on = false;       // resident PCG structures built (problem fits the register files)
   bool res_use = false;      // ... and in use
-  int res_fails = 0;         // launches that gave up waiting (one sends the rest of the run_admm call to the launch-per-step
-                             // kernels; the third sends the engine there for good)
+  int res_fails = 0;         // launches that gave up waiting, in a row (one sends the rest of the run_admm call to the launch-per-step
+                             // kernels; the third in a row sends the engine there for good; a call without one starts the count again)
+  long long res_gave_up = 0; // ... since create
+  long long res_slow = 0, res_slow_max = 0, res_repub = 0;   // State::res_slow / res_slow_max / res_repub added up over the windows
   ResCtx rc{};
   BrCtx bc{};                // block-resident form (res_kind 2)
   int res_kind = 0;          // 0: launch-per-step only, 1: k_pcg_resident, 2: k_pcg_blockres
@@ -2277,7 +2359,8 @@ static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr)
   if (!want) RES_NO("OSQP_AMD_RESIDENT=0");
   if (n < min_n || n > RES_MAXN) RES_NO("n outside [OSQP_AMD_RESIDENT_MIN_N, 15616]");
   if (!e->hrows.empty() || e->A.nwave < (int)e->A.blk.size()) RES_NO("A has rows of 8192 or more entries");   // (their outer products alone overflow the register files)
-  int nwg = plan_nwg;
+  int nwg = plan_nwg < 0 ? -plan_nwg : plan_nwg;      // (plan mode: nwg > 0 keeps that grid, nwg < 0 sizes the grid for a machine of -nwg CUs)
+  const bool fixed_grid = po && plan_nwg > 0;
   if (!po) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, e->device));
@@ -2326,14 +2409,41 @@ static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr)
     }
     return g + 1;
   };
-  long long lo = 1, hi = std::max<long long>(nnzK, 1);
-  for (int i = 0; i < n; i++) lo = std::max<long long>(lo, Kptr[i + 1] - Kptr[i]);
-  if (packs(hi) > nwg) RES_NO("more than 64 rows per workgroup");
-  while (lo < hi) { const long long mid = (lo + hi) / 2; if (packs(mid) <= nwg) hi = mid; else lo = mid + 1; }
-  const long long C = lo;
+  // The grid is sized to the problem: every exchange is an all-to-all between the participating CUs and costs 2.3 us among
+  // 4, 3.6 among 16, 4.2 among 64, 6.5 among 256 (profiles/r03_exchange_probe2.txt), while a thread's E entries cost about
+  // 0.06 us each per product.  So: the smallest grid that keeps E <= 16 (halving E from 16 no longer pays for the doubled
+  // grid), at most `nwg_max` = the CUs of the device; beyond that E grows (20, 24, ... at config 2: 256 workgroups, E = 20).
+  // OSQP_AMD_RESIDENT_NWG overrides (tests, probes).
+  const int nwg_max = nwg;
+  long long maxrow = 1;
+  for (int i = 0; i < n; i++) maxrow = std::max<long long>(maxrow, Kptr[i + 1] - Kptr[i]);
+  if (packs(std::max<long long>(nnzK, 1)) > nwg_max) RES_NO("more than 61 rows per workgroup");
   int E = 0;
-  for (int cand : RES_E_LIST) if ((long long)cand * RES_PT >= C) { E = cand; break; }
+  long long C = 0;
+  int force_nwg = 0;
+  if (const char *x = getenv("OSQP_AMD_RESIDENT_NWG")) force_nwg = std::max(0, std::min(nwg_max, atoi(x)));
+  for (int cand : RES_E_LIST) {
+    const long long cap = (long long)cand * RES_PT;
+    if (cap < maxrow) continue;
+    const int need = packs(cap);
+    if (need > nwg_max) continue;
+    if (!po && force_nwg > 0 && need > force_nwg) continue;
+    E = cand; nwg = need;
+    if (cand >= 16 || fixed_grid) break;
+    // E = 8 fits: keep it only if E = 16 would not halve the grid (tiny problems: the rows, not the entries, set the grid)
+    const int need16 = packs(16LL * RES_PT);
+    if (need16 * 2 > need) break;
+  }
   if (!E) RES_NO("a row block of K exceeds 448 x 64 entries");
+  if (fixed_grid) nwg = nwg_max;               // (a plan for the CPU tests that keeps the grid it was asked for)
+  else if (force_nwg > nwg) nwg = force_nwg;
+  {
+    // smallest block capacity that still needs no more than nwg blocks: balances the workgroups
+    long long lo = maxrow, hi = (long long)E * RES_PT;
+    while (lo < hi) { const long long mid = (lo + hi) / 2; if (packs(mid) <= nwg) hi = mid; else lo = mid + 1; }
+    C = lo;
+    if (fixed_grid) { E = 0; for (int cand : RES_E_LIST) if ((long long)cand * RES_PT >= C) { E = cand; break; } if (!E) RES_NO("a row block of K exceeds 448 x 64 entries"); }
+  }
   std::vector<ResWG> wg(nwg, ResWG{n, 0, 0, 0});
   {
     int g = 0, rows = 0; long long cnt = 0; wg[0].r0 = 0;
@@ -2420,6 +2530,7 @@ static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr)
   }
   ResCtx rc{};
   rc.nwg = nwg; rc.E = E; rc.npad = npad;
+  rc.npw = (nwg + 63) / 64;
   rc.pipe = 1;
   if (const char *x = getenv("OSQP_AMD_RESIDENT_PIPE")) rc.pipe = atoi(x) != 0;
   rc.u0_direct = 1;
@@ -2433,7 +2544,7 @@ static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr)
       dev_alloc(e, &d_krp, Kptr.size()) || dev_alloc(e, &d_kcj, Kcol.size()) || dev_alloc(e, &d_kps, Kps.size()) || dev_alloc(e, &d_kdst, kdst.size()) ||
       dev_alloc(e, &d_brk, brk.size()) || dev_alloc(e, &d_slot0, slot0.size()) ||
       dev_alloc(e, &d_segrow, segrow.size()) || dev_alloc(e, &d_rowpos, rowpos.size()) || dev_alloc(e, &rc.ubuf, (size_t)2 * rc.npad) ||
-      dev_alloc_polled(e, &rc.flags, (size_t)nwg * RES_FSTRIDE) || dev_alloc(e, &rc.dbg, (size_t)nwg * 4) || dev_alloc_polled(e, &rc.sbuf, (size_t)2 * nwg * RES_GSTRIDE)) return HIPENG_ERR_HIP;
+      dev_alloc_polled(e, &rc.flags, (size_t)nwg * RES_FSTRIDE) || dev_alloc(e, &rc.dbg, (size_t)nwg * RES_DBG) || dev_alloc_polled(e, &rc.sbuf, (size_t)2 * nwg * RES_GSTRIDE)) return HIPENG_ERR_HIP;
 #define UP(dst, src) HIPCHK(hipMemcpyAsync(dst, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, e->stream))
   UP(d_wg, wg); UP(d_rowpos, rowpos); UP(d_col, col); UP(d_rowl, rowl); UP(d_krp, Kptr); UP(d_kcj, Kcol); UP(d_kps, Kps); UP(d_kdst, kdst); UP(d_brk, brk); UP(d_slot0, slot0); UP(d_segrow, segrow);
 #undef UP
@@ -2498,7 +2609,7 @@ static int build_blockres(hipeng *e) {
   BrCtx bc{};
   bc.nwg = nwg;
   int *d_blk0 = nullptr;
-  if (dev_alloc(e, &d_blk0, blk0.size()) || dev_alloc_polled(e, &bc.sbuf, (size_t)2 * nwg * RES_GSTRIDE)) return HIPENG_ERR_HIP;
+  if (dev_alloc(e, &d_blk0, blk0.size()) || dev_alloc_polled(e, &bc.sbuf, (size_t)2 * nwg * RES_GSTRIDE) || dev_alloc(e, &bc.dbg, (size_t)nwg * RES_DBG)) return HIPENG_ERR_HIP;
   HIPCHK(hipMemcpyAsync(d_blk0, blk0.data(), blk0.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   bc.blk0 = d_blk0;
@@ -2965,6 +3076,64 @@ static int next_K(int want, int cap) {
   return K;
 }
 
+// A resident launch gave up (State::res_fail): say what the workgroups left behind, clean up, count the strike.
+// The record is meant to be decisive: for the workgroup whose wait timed out first it prints the word it last read from the
+// workgroup it missed NEXT TO the word that is in memory now (read by the host), where the missed workgroup itself stood,
+// when it published (its give-up clock minus the ticks it had waited) and both XCC ids -- "store landed but was never seen",
+// "store never landed" and "the other one was late" read differently.
+static int resident_gave_up(hipeng *e, const State &s, bool quiet) {
+  const int nwg = e->res_kind == 2 ? e->bc.nwg : e->rc.nwg;
+  int *ddbg = e->res_kind == 2 ? e->bc.dbg : e->rc.dbg;
+  std::vector<int> d((size_t)nwg * RES_DBG, 0);
+  bool have = ddbg && hipMemcpy(d.data(), ddbg, d.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+  const bool injected = have && e->res_kind == 1 && e->rc.inject > 0 && d[(size_t)RES_DBG * (nwg - 1) + 3] == 4;
+  if (!quiet || !injected) {
+    fprintf(stderr, "osqp_amd: a resident PCG launch gave up waiting for its workgroups%s; %s with the launch-per-step kernels "
+                    "[wait %d (1 flags, 2 granules) of exchange %d: workgroup %d missed workgroup %d]\n",
+            injected ? " (injected by OSQP_AMD_RESIDENT_INJECT)" : " (GPU shared with another stream or process?)",
+            e->res_fails >= 2 ? "continuing for good" : "finishing this call", s.res_dbg[0], s.res_dbg[1], s.res_dbg[2], s.res_dbg[3]);
+    if (have) {
+      std::map<long long, int> hist;
+      for (int g = 0; g < nwg; g++) hist[((long long)d[(size_t)RES_DBG * g] << 16) | ((d[(size_t)RES_DBG * g + 1] & 255) << 8) | (d[(size_t)RES_DBG * g + 3] & 255)]++;
+      fprintf(stderr, "osqp_amd:   workgroups by (exchange, mode, how they left: 1/2 own flag/granule wait timed out, 3 saw the give-up word, 4 injected, 0 never waited):");
+      for (auto &h : hist) fprintf(stderr, " (%lld, %lld, %lld) x %d;", h.first >> 16, (h.first >> 8) & 255, h.first & 255, h.second);
+      fprintf(stderr, " epoch base %u\n", s.res_epoch);
+      const int wg = s.res_dbg[2], ow = s.res_dbg[3];
+      if (wg >= 0 && wg < nwg) {
+        const int *w = &d[(size_t)RES_DBG * wg];
+        fprintf(stderr, "osqp_amd:   waiter %d (XCC %d): waited %.1f us, %d rounds, last read 0x%08x from workgroup %d (expected tag 0x%08x), gave up at clock 0x%08x\n",
+                wg, w[7], w[6] * 0.01, w[9], (unsigned)w[5], w[4], s.res_epoch + (unsigned)w[0], (unsigned)w[8]);
+        if (ow >= 0 && ow < nwg) {
+          const int *o = &d[(size_t)RES_DBG * ow];
+          unsigned long long memword = 0; bool got = false;
+          if (s.res_dbg[0] == 1 && e->res_kind == 1) { unsigned f = 0; got = hipMemcpy(&f, e->rc.flags + (size_t)ow * RES_FSTRIDE, 4, hipMemcpyDeviceToHost) == hipSuccess; memword = f; }
+          else {
+            const double *sb = e->res_kind == 2 ? e->bc.sbuf : e->rc.sbuf;
+            const unsigned tag = s.res_epoch + (unsigned)w[0];
+            int gi = 0; while (gi < 15 && !((w[10] >> gi) & 1)) gi++;
+            got = hipMemcpy(&memword, reinterpret_cast<const unsigned long long *>(sb) + ((size_t)(tag & 1u) * nwg + ow) * RES_GSTRIDE + gi, 8, hipMemcpyDeviceToHost) == hipSuccess;
+            memword >>= 32;
+          }
+          fprintf(stderr, "osqp_amd:   owner %d (XCC %d): stood in exchange %d (left: %d), published at clock 0x%08x (its give-up 0x%08x minus %.1f us of its own wait); "
+                          "the word in memory now: %s0x%08llx\n", ow, o[7], o[0], o[3], (unsigned)(o[8] - o[6]), (unsigned)o[8], o[6] * 0.01, got ? "" : "(unreadable) ", memword);
+        }
+      }
+    }
+  }
+  e->res_use = false;
+  e->res_fails += 1;
+  e->res_gave_up += 1;
+  HIPCHK(hipMemsetAsync(&e->c.st->res_fail, 0, sizeof(int), e->stream));
+  // the launch that gave up left flags and granules with tags beyond the epoch it started from (it never wrote the
+  // epoch back): the next resident launch must not take them for its own -- start it far beyond (tags compare modulo 2^32)
+  e->h_state->res_epoch = s.res_epoch + (1u << 20);
+  HIPCHK(hipMemcpyAsync(&e->c.st->res_epoch, &e->h_state->res_epoch, sizeof(unsigned), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemsetAsync(e->c.st->res_dbg, 0, sizeof(int) * 4, e->stream));
+  if (ddbg) HIPCHK(hipMemsetAsync(ddbg, 0, d.size() * sizeof(int), e->stream));
+  return 0;
+}
+
 extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   if (!e || count < 0) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
@@ -2988,6 +3157,7 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   // that is shared for good, there is a rare transient (about one exchange in 1e5 on small, fast problems: a workgroup's
   // flag or granule stays invisible to some CUs): the next call tries resident launches again, three strikes end that.
   if (e->res_on && !e->res_use && e->res_fails < 3) e->res_use = true;
+  bool had_fail = false;
   const long long start = e->admm_total, target = start + (long long)count;
   *e->h_target = target;
   HIPCHK(hipMemcpyAsync(&e->c.st->admm_target, e->h_target, sizeof(long long), hipMemcpyHostToDevice, e->stream));
@@ -3023,39 +3193,12 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     for (; left > 0; left--) { HIPCHK(hipGraphLaunch(g1, e->stream)); e->stats.graph_launches += 1; }
     if (read_state(e, &s)) return HIPENG_ERR_HIP;
     if (lease.owns_lock()) lease.unlock();
-    if (s.res_fail) {
-      // the resident launch found its grid not co-resident (the GPU is shared): launch-per-step kernels from here on
-      fprintf(stderr, "osqp_amd: resident PCG launch timed out waiting for its workgroups (GPU shared with another stream or process?); "
-                      "%s with the launch-per-step kernels [wait %d of exchange %d: workgroup %d missed workgroup %d; PCG iterations so far %d]\n",
-              e->res_fails >= 2 ? "continuing for good" : "finishing this window", s.res_dbg[0], s.res_dbg[1], s.res_dbg[2], s.res_dbg[3], std::max(s.iters[0], s.iters[1]));
-      if (e->res_kind == 1) {   // where every workgroup stood when it gave up
-        std::vector<int> d((size_t)e->rc.nwg * 4), fl((size_t)e->rc.nwg * RES_FSTRIDE);
-        if (hipMemcpy(d.data(), e->rc.dbg, d.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess &&
-            hipMemcpy(fl.data(), e->rc.flags, fl.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
-          std::map<long long, int> hist;
-          for (int g = 0; g < e->rc.nwg; g++) hist[((long long)d[4 * g] << 16) | (d[4 * g + 1] << 8) | (d[4 * g + 3] & 255)]++;
-          fprintf(stderr, "osqp_amd:   workgroups by (exchange, mode, reported):");
-          for (auto &h : hist) fprintf(stderr, " (%lld, %lld, %lld) x %d;", h.first >> 16, (h.first >> 8) & 255, h.first & 255, h.second);
-          fprintf(stderr, "\nosqp_amd:   odd ones:");
-          const long long common = std::max_element(hist.begin(), hist.end(), [](const std::pair<const long long, int> &a, const std::pair<const long long, int> &b) { return a.second < b.second; })->first;
-          int shown = 0;
-          for (int g = 0; g < e->rc.nwg && shown < 8; g++) {
-            const long long key = ((long long)d[4 * g] << 16) | (d[4 * g + 1] << 8) | (d[4 * g + 3] & 255);
-            if (key != common) { fprintf(stderr, " wg %d: exchange %d mode %d iters %d flag %u;", g, d[4 * g], d[4 * g + 1], d[4 * g + 2], (unsigned)fl[(size_t)g * RES_FSTRIDE]); shown++; }
-          }
-          fprintf(stderr, " (epoch base %u)\n", s.res_epoch);
-        }
-      }
-      e->res_use = false;
-      e->res_fails += 1;
-      HIPCHK(hipMemsetAsync(&e->c.st->res_fail, 0, sizeof(int), e->stream));
-      // the launch that gave up left flags and granules with tags beyond the epoch it started from (it never wrote the
-      // epoch back): the next resident launch must not take them for its own -- start it far beyond (tags compare modulo 2^32)
-      e->h_state->res_epoch = s.res_epoch + (1u << 20);
-      HIPCHK(hipMemcpyAsync(&e->c.st->res_epoch, &e->h_state->res_epoch, sizeof(unsigned), hipMemcpyHostToDevice, e->stream));
-      HIPCHK(hipStreamSynchronize(e->stream));
-      HIPCHK(hipMemsetAsync(e->c.st->res_dbg, 0, sizeof(int) * 4, e->stream));
+    e->res_slow += s.res_slow; e->res_slow_max = std::max<long long>(e->res_slow_max, s.res_slow_max); e->res_repub += s.res_repub;
+    if (s.res_slow || s.res_repub) {
+      if (e->trace) fprintf(stderr, "[osqp_amd] resident waits: %d took more than 50 us (longest %.1f us), %d re-publications\n", s.res_slow, s.res_slow_max * 0.01, s.res_repub);
+      HIPCHK(hipMemsetAsync(&e->c.st->res_slow, 0, 3 * sizeof(int), e->stream));
     }
+    if (s.res_fail) { had_fail = true; if (resident_gave_up(e, s, !e->trace)) return HIPENG_ERR_HIP; }
     const long long done_now = s.admm_done - start;
     const bool stalls = count - done_now > remaining - burst;       // some launches were continuations
     remaining = count - done_now;
@@ -3077,6 +3220,7 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     }
     if (++guard > 1000000) { fprintf(stderr, "osqp_amd: the ADMM run loop did not terminate\n"); return HIPENG_ERR_HIP; }
   }
+  if (!had_fail && e->res_use) e->res_fails = 0;     // strikes count in a row: a call of clean resident windows starts over
   e->admm_total = s.admm_done;
   e->stats.admm_done = (c_int)(s.admm_done - start);
   e->stats.pcg_iters_total = (c_int)s.iters_total;
@@ -3282,17 +3426,11 @@ extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) 
   HIPCHK(hipGraphExecDestroy(ge));
   *usec = 1e3 * (double)ms / reps;
   if (which == 8) {
-    // a resident launch of the timed run may have given up (the rare transient of DESIGN.md 2a): the number is void then;
-    // leave the engine as the run loop would (flag cleared, epoch beyond the abandoned tags, one strike)
+    // a resident launch of the timed run may have given up: the number is void then; leave the engine as the run loop would
     State s;
     if (read_state(e, &s)) return HIPENG_ERR_HIP;
     if (s.res_fail) {
-      e->res_fails += 1;
-      HIPCHK(hipMemsetAsync(&e->c.st->res_fail, 0, sizeof(int), e->stream));
-      HIPCHK(hipMemsetAsync(e->c.st->res_dbg, 0, sizeof(int) * 4, e->stream));
-      e->h_state->res_epoch = s.res_epoch + (1u << 20);
-      HIPCHK(hipMemcpyAsync(&e->c.st->res_epoch, &e->h_state->res_epoch, sizeof(unsigned), hipMemcpyHostToDevice, e->stream));
-      HIPCHK(hipStreamSynchronize(e->stream));
+      if (resident_gave_up(e, s, false)) return HIPENG_ERR_HIP;
       return HIPENG_ERR_HIP;
     }
   }
@@ -3349,13 +3487,14 @@ extern "C" int hipeng_is_split(hipeng *e) { return e && e->split ? 1 : 0; }
 // [5] LDS bytes per workgroup, [6] PCG iterations of the most recent linear solve, [7] pipelined phase switched off for this K,
 // [8] true-residual checks that failed since create, [9] form: 1 k_pcg_resident, 2 k_pcg_blockres,
 // [10] launches that gave up waiting (the third one ends the mode for this engine)
-extern "C" int hipeng_resident_info(hipeng *e, long long out[12]) {
+extern "C" int hipeng_resident_info(hipeng *e, long long out[16]) {
   if (!e || !out) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   State s;
   if (read_state(e, &s)) return HIPENG_ERR_HIP;
   out[0] = e->res_on; out[1] = e->res_on && e->res_fails < 3; out[2] = e->rc.E; out[3] = e->rc.nwg; out[4] = e->res_nnz; out[5] = (long long)e->res_lds;
-  out[6] = std::max(s.iters[0], s.iters[1]); out[7] = s.res_pipe_off; out[8] = s.res_chk_fail; out[9] = e->res_kind; out[10] = e->res_fails; out[11] = 0;
+  out[6] = std::max(s.iters[0], s.iters[1]); out[7] = s.res_pipe_off; out[8] = s.res_chk_fail; out[9] = e->res_kind; out[10] = e->res_gave_up; out[11] = e->res_slow + s.res_slow;
+  out[12] = std::max<long long>(e->res_slow_max, s.res_slow_max); out[13] = e->res_repub + s.res_repub; out[14] = e->res_fails; out[15] = 0;
   if (e->res_kind == 2) { out[2] = 64; out[3] = e->bc.nwg; out[4] = 0; out[5] = 0; }
   return 0;
 }

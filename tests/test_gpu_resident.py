@@ -39,9 +39,10 @@ def _info(solver):
     L = osqp_amd.lib()
     L.hipeng_resident_info.restype = C.c_int
     L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
-    out = (C.c_longlong * 12)()
+    out = (C.c_longlong * 16)()
     assert L.hipeng_resident_info(solver.engine(), out) == 0
-    return dict(built=out[0], in_use=out[1], E=out[2], nwg=out[3], nnzK=out[4], lds=out[5], last_iters=out[6], pipe_off=out[7], checks_failed=out[8], form=out[9], gave_up=out[10])
+    return dict(built=out[0], in_use=out[1], E=out[2], nwg=out[3], nnzK=out[4], lds=out[5], last_iters=out[6], pipe_off=out[7], checks_failed=out[8], form=out[9], gave_up=out[10],
+                slow_waits=out[11], slow_max_ticks=out[12], republished=out[13], strikes=out[14])
 
 
 def _qp(n, m, seed, eq=0, dens=0.02):
@@ -111,7 +112,8 @@ def test_resident_modes_match_oracle(gpu_lib, oracle_mod, pipe):
         sg.update(q=q2); so.update(q=q2)
         rg, ro = sg.solve(), so.solve()
         assert rg.info.iter == ro.info.iter and _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
-        assert _info(sg)["built"]
+        inf = _info(sg)
+        assert inf["in_use"] and inf["gave_up"] == 0, inf
 
 
 def test_resident_hands_ill_conditioned_solves_to_the_robust_recurrences(gpu_lib, oracle_mod):
@@ -134,7 +136,8 @@ def test_resident_hands_ill_conditioned_solves_to_the_robust_recurrences(gpu_lib
     assert rg.info.status == ro.info.status == "solved"
     assert rg.info.iter == ro.info.iter
     assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-5
-    assert _info(sg)["built"]            # still resident: the hand-over happens inside the launch
+    inf = _info(sg)
+    assert inf["in_use"] and inf["gave_up"] == 0, inf            # still resident: the hand-over happens inside the launch
 
 
 def test_resident_on_tiny_problems(gpu_lib, oracle_mod):
@@ -208,13 +211,14 @@ def test_a_launch_that_gives_up_costs_one_window(gpu_lib, oracle_mod):
     assert rg.info.status == ro.info.status == "solved" and rg.info.iter == ro.info.iter > 40
     assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
     inf = _info(sg)
-    assert inf["gave_up"] >= 1 and inf["in_use"] == 1, inf      # (>=: the rare spontaneous give-up of DESIGN.md 2a may add one)
+    assert inf["gave_up"] == 1 and inf["in_use"] == 1, inf
     for k in range(3):          # resident again: same trajectories as the oracle
         q2 = pb["q"] * (1.0 + 0.1 * (k + 1))
         sg.update(q=q2); so.update(q=q2)
         rg, ro = sg.solve(), so.solve()
         assert rg.info.iter == ro.info.iter and _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
-    assert _info(sg)["gave_up"] < 3
+    inf = _info(sg)
+    assert inf["gave_up"] == 1 and inf["strikes"] == 0, inf      # clean calls since: the strike count started over
 
 
 def test_resident_off_by_environment_and_for_large_n(gpu_lib):

@@ -27,10 +27,11 @@ def _plan(P, A, nwg=256):
         return st, None
     nnz, E = st[3], st[1]
     Kptr = np.zeros(n + 1, dtype=np.int32); Kcol = np.zeros(nnz, dtype=np.int32); kdst = np.zeros(nnz, dtype=np.int32)
-    rowpos = np.zeros(n, dtype=np.uint16); slotcol = np.zeros(nwg * E * st[7], dtype=np.uint16); wg4 = np.zeros(4 * nwg, dtype=np.int32)
+    cap = abs(nwg)                      # (nwg < 0: the engine sizes the grid itself, at most -nwg workgroups)
+    rowpos = np.zeros(n, dtype=np.uint16); slotcol = np.zeros(cap * E * st[7], dtype=np.uint16); wg4 = np.zeros(4 * cap, dtype=np.int32)
     assert f(C.byref(Pu.struct), C.byref(Ah.struct), nwg, stats, Kptr.ctypes.data, Kcol.ctypes.data, kdst.ctypes.data, nnz,
              rowpos.ctypes.data, slotcol.ctypes.data, wg4.ctypes.data) == 0
-    return st, dict(Kptr=Kptr, Kcol=Kcol, kdst=kdst, rowpos=rowpos, slotcol=slotcol, wg=wg4.reshape(nwg, 4))
+    return st, dict(Kptr=Kptr, Kcol=Kcol, kdst=kdst, rowpos=rowpos, slotcol=slotcol, wg=wg4.reshape(cap, 4))
 
 
 def _qp(n, m, seed, dens):
@@ -107,3 +108,29 @@ def test_plan_refuses_what_does_not_fit():
     P, A = _qp(100, 50, 5, 0.1)
     st, _ = _plan(P, A, 256)
     assert st[0] == 0
+
+
+def test_the_grid_is_sized_to_the_problem():
+    """nwg < 0: the grid the engine itself chooses on a machine of -nwg CUs.  Every exchange inside a resident launch is an
+    all-to-all between the participating CUs, so a small K gets a small grid: the fewest workgroups that keep 61 rows and
+    16 x 448 entries each (8 x 448 where halving the entries would not halve the grid); only a K that does not fit 256 such
+    blocks lets the entries per thread grow."""
+    grids = []
+    for n, m, dens in ((300, 200, 0.02), (900, 700, 0.02), (2500, 1500, 0.004)):
+        P, A = _qp(n, m, n, dens)
+        st, pl = _plan(P, A, -256)
+        assert st[0] == 1
+        nwg = st[4]                      # workgroups that own rows = the grid
+        assert pl["wg"][:nwg, 1].min() >= 1 and (pl["wg"][nwg:, 1] == 0).all()
+        assert st[1] <= 16 and st[5] <= 61 and st[6] <= st[1] * 448
+        assert nwg >= -(-n // 61)
+        # one workgroup fewer would not do at E = 16
+        if nwg > -(-n // 61):
+            assert st[3] > (nwg - 1) * 16 * 448 * 0.5     # (greedy contiguous packing wastes at most a row per block)
+        assert st[2] == sum(((int(r) + 3 + 15) // 16) * 16 for r in pl["wg"][:nwg, 1])   # the exchanged vector shrinks with the grid
+        grids.append(nwg)
+    assert grids[0] < 16 and grids[0] < grids[1] < 256
+    # a fixed grid of 256 for the same problem: same K, more (mostly empty) participants
+    P, A = _qp(300, 200, 300, 0.02)
+    st256, _ = _plan(P, A, 256)
+    assert st256[3] == _plan(P, A, -256)[0][3] and st256[2] > _plan(P, A, -256)[0][2]

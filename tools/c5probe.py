@@ -19,7 +19,7 @@ for name in which:
     us = C.c_double(); L.hipeng_time_kernel(s.engine(), 5, 50, C.byref(us)); print("   k_pcg_init: %.1f us" % us.value)
     if st.get("resident"):
         L.hipeng_resident_info.restype = C.c_int; L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
-        info = (C.c_longlong * 12)(); up = C.c_double()
+        info = (C.c_longlong * 16)(); up = C.c_double()
         s.update_settings(max_iter=100); s.solve(); s.update_settings(max_iter=4000)      # a state in the middle of a solve
         L.hipeng_time_kernel(s.engine(), 8, 50, C.byref(up)); L.hipeng_resident_info(s.engine(), info)
         print("   resident launch (form %d): %.1f us for %d PCG iterations -> %.2f us each" % (info[9], up.value - us.value, info[6], (up.value - us.value) / max(1, info[6])))

@@ -22,6 +22,6 @@ for k in range(solves):
         if not st["resident"]: break
 import ctypes as C
 L = osqp_amd.lib(); L.hipeng_resident_info.restype = C.c_int; L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
-info = (C.c_longlong * 12)(); L.hipeng_resident_info(s.engine(), info)
+info = (C.c_longlong * 16)(); L.hipeng_resident_info(s.engine(), info)
 print("%d solves of %d ADMM iterations, %d PCG iterations in all, %.1f s: %d anomalies, %d failed true-residual checks, %d launches that gave up waiting (PIPE=%s)" % (
     k + 1, ref[2], s.stats()["pcg_iters_total"], time.perf_counter() - t0, bad, info[8], info[10], os.environ.get("OSQP_AMD_RESIDENT_PIPE", "1")))
