@@ -146,6 +146,11 @@ int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec);
 /* Algorithmic bytes of one launch of the kernels above. */
 int hipeng_kernel_bytes(hipeng *e, int which, double *bytes);
 int hipeng_is_split(hipeng *e);   /* k_cg_A as two launches (update-only + apply-only)? */
+/* Slack-like variables (one entry in their column of A, no coupling in P) are eliminated from the linear system exactly
+ * (engine.hip, k_elim_refresh; launch-per-step engines).  hipeng_row_eliminated: does row i of A carry such a variable?
+ * hipeng_elim_count: how many variables are eliminated. */
+int hipeng_row_eliminated(hipeng *e, c_int i);
+c_int hipeng_elim_count(hipeng *e);
 /* Resident PCG (the reduced matrix K = P + sigma I + A' rho A held in registers, one launch per linear
  * solve; engine.hip, k_pcg_resident).  out[0] structures built, [1] in use, [2] entries of K per thread,
  * [3] workgroups, [4] nnz(K), [5] LDS bytes per workgroup, [6] PCG iterations of the most recent linear

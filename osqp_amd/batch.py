@@ -105,10 +105,14 @@ class BatchOSQP:
         return self
 
     def _many_update(self, Q, L, U):
-        rc = 0
+        # the first failing member's code comes back (and which member it was stays readable in `last_update_failed`)
+        self.last_update_failed = None
         for b, s in enumerate(self._many):
-            rc |= s.update(q=None if Q is None else Q[b], l=None if L is None else L[b], u=None if U is None else U[b])
-        return rc
+            rc = s.update(q=None if Q is None else Q[b], l=None if L is None else L[b], u=None if U is None else U[b])
+            if rc:
+                self.last_update_failed = b
+                return rc
+        return 0
 
     def _many_results(self):
         rs = self._last
@@ -163,6 +167,9 @@ class BatchOSQP:
         """The result arrays as they sit in HBM -- X [B, n], Y [B, m], info8 [B, 8] -- as objects carrying
         `__cuda_array_interface__` (no copy; `torch.as_tensor(a, device="cuda")` wraps them for a device-side
         gather).  Valid until the next solve / cleanup."""
+        if self._many is not None:
+            raise RuntimeError("this batch runs one single-QP engine per member (n > %d): its results are host arrays "
+                               "(results()); there is no packed device image to wrap" % BATCH_MAX_N)
         f = self._lib.osqp_amd_batch_device_ptrs
         f.restype = abi.c_int
         f.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]

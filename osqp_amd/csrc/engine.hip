@@ -117,6 +117,9 @@ struct State {
   int    res_slow;         // resident PCG: waits that ended well but took more than 50 us (the host adds them up: hipeng_resident_info)
   int    res_slow_max;     // ... the longest of them, in ticks of the 100 MHz clock
   int    res_repub;        // ... flags / granules that a workgroup stored again because its own wait went on (every 64th round)
+  int    res_slow_hist[4]; // ... slow waits by length: 50-200 us, 200-500 us, 0.5-2 ms, longer
+  unsigned res_slow_xcc;   // ... bit k: a wavefront on XCC k had one
+  int    res_slow_last[4]; // ... the latest: exchange number, workgroup, first workgroup it had missed at its 16th round, wait kind (1 flags, 2 granules)
 };
 
 struct Params {          // mutable scalars (host writes, kernels read)
@@ -142,6 +145,10 @@ struct Ctx {             // static pointers / sizes, passed by value
   double *pdir, *ut;               // Chronopoulos-Gear PCG: p, [u|t]
   G4     *g4;                      // ... and {r, w, s, Minv} records, ping-ponged on parity (2n)
   int     init_stride;             // element stride of init_r (4 when it points into g4)
+  // Slack-like variables eliminated from the linear system (k_elim_refresh): nelim = 0 switches all of it off (rhoe == rho then)
+  int     nelim;
+  const int *erow, *ecol, *epos;   // [n] row of an eliminated variable (-1: not eliminated); [m] the row's eliminated variable (-1: none), slot of that entry in A.val
+  double *rhoe, *ecoef, *edinv, *xte;   // [m] effective rho of the row, A(i, ecol[i]), 1 / D_y, x~ of the row's eliminated variable
   double *D, *Dinv, *E, *Einv;
   double *part_rz, *part_rr, *part_bb, *part_pkp, *part_s0, *part_s1, *part_s2, *part_gam, *part_del;
   const double *fin_rr;  // where k_admm_finalize finds the partials of the last ||r||^2, and how many
@@ -454,8 +461,9 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c, int bench) {
       if (longrow ? threadIdx.x == 0 : rlane == 0) {
         if (DENSE) for (int k = 0; k < c.nh; ++k) { const double hc = c.hcol[(size_t)k * c.n + j]; sA += hc * c.vx[c.n + c.hrow[k]]; sB += hc * c.vb[c.n + c.hrow[k]]; }
         const double base = prm.use_cvec ? c.cvec[j] : (prm.sigma * c.xy[j] - c.q[j]);
-        const double bj = base + sB;
-        const double rj = bj - prm.sigma * c.vx[j] - sA;
+        const bool gone = c.nelim && c.erow[j] >= 0;           // eliminated from the system: no residual, no direction
+        const double bj = gone ? 0.0 : base + sB;
+        const double rj = gone ? 0.0 : bj - prm.sigma * c.vx[j] - sA;
         const double zj = c.minv[j] * rj;
         c.init_r[(size_t)j * c.init_stride] = rj;
         c.init_z[j] = zj;
@@ -546,7 +554,7 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
   int rp0 = 0, rp1 = 0;
   double prho = 0.0;                   // rho of this lane group's first row
   if (small) {
-    if (b.r0 + rg < b.r1) { rp0 = c.A.rowptr[b.r0 + rg]; rp1 = c.A.rowptr[b.r0 + rg + 1]; prho = c.rho[b.r0 + rg]; }
+    if (b.r0 + rg < b.r1) { rp0 = c.A.rowptr[b.r0 + rg]; rp1 = c.A.rowptr[b.r0 + rg + 1]; prho = c.rhoe[b.r0 + rg]; }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int k = threadIdx.x + e * TB;
@@ -656,7 +664,7 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
       if (bi == (int)blockIdx.x && i == b.r0 + rg) { a0 = rp0; a1 = rp1; }
       else { a0 = c.A.rowptr[i]; a1 = c.A.rowptr[i + 1]; }
       const double acc = row_sum_par(lprod, a0 - b.k0, a1 - b.k0, rlane, RL);
-      if (rlane == 0) t[i] = ((bi == (int)blockIdx.x && i == b.r0 + rg) ? prho : c.rho[i]) * acc;
+      if (rlane == 0) t[i] = ((bi == (int)blockIdx.x && i == b.r0 + rg) ? prho : c.rhoe[i]) * acc;
     }
     __syncthreads();
   }
@@ -670,7 +678,7 @@ __global__ void __launch_bounds__(TB) k_cg_A(Ctx c, int it, int flags) {
       const double sj = first ? g.w : (g.w + beta * g.s);
       return g.m * (g.r - alpha * sj);
     });
-    if ((threadIdx.x & 63) == 0) t[lb.r0] = c.rho[lb.r0] * acc;
+    if ((threadIdx.x & 63) == 0) t[lb.r0] = c.rhoe[lb.r0] * acc;
   }
   // huge rows (a budget constraint over every variable, ...): every workgroup takes a
   // strided slice and leaves one partial; k_huge_reduce adds them in a fixed order
@@ -706,7 +714,7 @@ __global__ void __launch_bounds__(TB) k_huge_reduce(Ctx c, int flags) {
   double s = 0.0;
   for (int i = threadIdx.x; i < c.gridA; i += TB) s += part[i];
   s = block_sum(s, red);
-  if (threadIdx.x == 0) c.ut[c.n + row] = c.rho[row] * s;
+  if (threadIdx.x == 0) c.ut[c.n + row] = c.rhoe[row] * s;
 }
 
 // DENSE: P has dense diagonal blocks (their column walk keeps 64 loads per lane in flight and
@@ -737,7 +745,7 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
   for (int k = 0; k < MAX_HUGE_FOLD; ++k) {
     hs[k] = 0.0; ph[k] = 0.0; hrho[k] = 0.0;
     if (FOLD && k < c.nh) {
-      hrho[k] = c.rho[c.hrow[k]];
+      hrho[k] = c.rhoe[c.hrow[k]];
       for (int i = threadIdx.x; i < c.gridA; i += TB) hs[k] += c.part_h[(size_t)k * c.gridA + i];
     }
   }
@@ -790,7 +798,7 @@ __global__ void __launch_bounds__(TB) k_cg_B(Ctx c, int it, int flags) {
       if (rlane == 0) {
         const bool first = bi == (int)blockIdx.x && j == b.r0 + rg;
         const double uj = first ? pu : c.ut[j], rj = first ? pr : gc[j].r;
-        const double wj = (acc + sigma * uj) + hterm(j, first);
+        const double wj = (c.nelim && c.erow[j] >= 0) ? 0.0 : (acc + sigma * uj) + hterm(j, first);
         gc[j].w = wj;
         pg += rj * uj; pd += wj * uj; prr += rj * rj;
       }
@@ -855,6 +863,15 @@ __device__ __forceinline__ double huge_row_sum(const Ctx &c, int bi, double *red
   return block_sum(s, red);
 }
 
+// what the next right-hand side carries for row i: rho z - y, minus rho a b_y / D_y where the row has an eliminated variable y
+__device__ __forceinline__ double elim_vb(const Ctx &c, const Params &prm, int i, double rho, double vbn, double x_y) {
+  const int y = c.ecol[i];
+  if (y < 0) return vbn;
+  const double a = c.ecoef[i];
+  const double by = (prm.use_cvec ? c.cvec[y] : (prm.sigma * x_y - c.q[y])) + a * vbn;
+  return vbn - rho * a * by * c.edinv[i];
+}
+
 // Last kernel of an ADMM iteration: z~ = A x~, then update_x / update_z (+project)
 // / update_y (auxil.c:185-225, proj.c:4-14) and the m-parts of the next
 // right-hand side.  If the PCG has not converged within the unrolled
@@ -896,6 +913,7 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
   const double *xts = from_start ? c.vx : c.va;
   double *x = c.xy, *y = c.xy + c.n;
   for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
+    if (c.nelim && c.erow[j] >= 0) continue;      // eliminated from the linear system: its row's thread back-substitutes and updates it below
     const double xo = x[j], xt = xts[j];
     const double xn = alpha * xt + oma * xo;
     c.dxy[j] = xn - xo;
@@ -917,16 +935,28 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
       else zt = row_sum_par(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0, rlane, RL);
       if (longrow ? threadIdx.x == 0 : rlane == 0) {
         const double rho = c.rho[i], rinv = c.rhoinv[i], yo = y[i], zo = c.z[i];
+        const int ye = c.nelim ? c.ecol[i] : -1;
+        double rz = rho * zt, xny = 0.0;
+        if (ye >= 0) {
+          // zt so far is (A_X x~_X)_i: the PCG vector is zero at the eliminated variable.  Back substitution
+          // x~_y = (b_y - rho a (A_X x~_X)_i) / D_y with the b_y of the system just solved, then the variable's own update_x.
+          const double a = c.ecoef[i], xoy = x[ye];
+          const double by = (prm.use_cvec ? c.cvec[ye] : (prm.sigma * xoy - c.q[ye])) + a * (rho * zo - yo);
+          const double xty = (by - rho * a * zt) * c.edinv[i];
+          rz = c.rhoe[i] * zt;                     // what the operator of the reduced system applies to this row
+          zt += a * xty;
+          xny = alpha * xty + oma * xoy;
+          c.dxy[ye] = xny - xoy; x[ye] = xny; c.xte[i] = xty;
+        }
         double v = alpha * zt + oma * zo + rinv * yo;
         v = fmax(v, c.l[i]);
         const double zn = fmin(v, c.u[i]);
         const double dy = rho * (alpha * zt + oma * zo - zn);
         const double yn = yo + dy;
         c.z[i] = zn; y[i] = yn; c.dy[i] = dy; c.zt[i] = zt;
-        const double rz = rho * zt;
         c.va[c.n + i] = rz;
         if (ex) { c.vx[c.n + i] = rz + th * (rz - c.vold[c.n + i]); c.vold[c.n + i] = rz; }
-        c.vb[c.n + i] = rho * zn - yn;
+        c.vb[c.n + i] = ye >= 0 ? elim_vb(c, prm, i, rho, rho * zn - yn, xny) : rho * zn - yn;
       }
     }
     __syncthreads();
@@ -1029,9 +1059,14 @@ __device__ __forceinline__ void res_note(State *st, int *dbg, int g, int verdict
   d[7] = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20);        // HW_REG_XCC_ID, bits 3:0
   d[8] = (int)(unsigned)now; d[9] = (int)rounds; d[10] = gidx;
 }
-__device__ __forceinline__ void res_slow_note(State *st, long long t0) {
+__device__ __forceinline__ void res_slow_note(State *st, long long t0, int nx, int g, int missed, int kind) {
   const long long el = wall_clock64() - t0;
-  if (el > RES_SLOW_TICKS && el < (1LL << 40)) { atomicAdd(&st->res_slow, 1); atomicMax(&st->res_slow_max, (int)(el > 0x7fffffffLL ? 0x7fffffffLL : el)); }
+  if (el > RES_SLOW_TICKS && el < (1LL << 40)) {
+    atomicAdd(&st->res_slow, 1); atomicMax(&st->res_slow_max, (int)(el > 0x7fffffffLL ? 0x7fffffffLL : el));
+    atomicAdd(&st->res_slow_hist[el < 20000 ? 0 : (el < 50000 ? 1 : (el < 200000 ? 2 : 3))], 1);
+    atomicOr(&st->res_slow_xcc, 1u << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15));
+    st->res_slow_last[0] = nx; st->res_slow_last[1] = g; st->res_slow_last[2] = missed; st->res_slow_last[3] = kind;
+  }
 }
 
 // K values in the resident layout.  K_ij = P_ij + sigma [i == j] + sum_k rho_k (A_ki A_kj): the sum runs over the rows k
@@ -1195,6 +1230,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
       // before it issued the next), and only until that flag has been seen; the own flag is not polled
       const int o = t;                         // flag of workgroup t
       bool pend = o < nwg && o != g;
+      int miss16 = -1;
       unsigned seen = 0, rounds = 0;
       long long t0 = wall_clock64();
       int late = 0;
@@ -1215,6 +1251,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
           gave = true;
           break;
         }
+        if (rounds == 16u) { const unsigned long long ms = __ballot(pend); miss16 = ms ? 64 * wv + (int)__ffsll((long long)ms) - 1 : -1; }
         if ((rounds & 63u) == 0 && wv == 0 && lane == 0) {       // a long wait: say it again
           __hip_atomic_store(rc.flags + (size_t)g * RES_FSTRIDE, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicAdd(&st->res_repub, 1);
@@ -1222,7 +1259,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
         if ((rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __builtin_amdgcn_s_sleep(1);
       }
-      if (rounds >= 16u && lane == 0 && !gave) res_slow_note(st, t0);
+      if (rounds >= 16u && lane == 0 && !gave) res_slow_note(st, t0, nx, g, miss16, 1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __syncthreads();
@@ -1306,6 +1343,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
       const int o = t;                         // the workgroup whose granules this thread fetches
       const __amdgpu_buffer_rsrc_t rg = res_rsrc(gb, (size_t)nwg * RES_GSTRIDE * 8);
       unsigned pend = o < nwg ? 63u : 0u;
+      int miss16 = -1;
       unsigned *svw = reinterpret_cast<unsigned *>(sval) + 6 * o;
       unsigned seen = 0, rounds = 0;
       long long t0 = wall_clock64();
@@ -1331,6 +1369,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
           gave = true;
           break;
         }
+        if (rounds == 16u) { const unsigned long long ms = __ballot(pend != 0); miss16 = ms ? 64 * wv + (int)__ffsll((long long)ms) - 1 : -1; }
         if ((rounds & 63u) == 0 && wv == 0) {          // a long wait: say it again
           if (lane < 6) {
             const double v = lane < 2 ? pg : (lane < 4 ? pd : prr);
@@ -1342,7 +1381,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
         if ((rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // a poll that stays unanswered this long: drop whatever this CU still caches
         __builtin_amdgcn_s_sleep(1);
       }
-      if (rounds >= 16u && lane == 0 && !gave) res_slow_note(st, t0);
+      if (rounds >= 16u && lane == 0 && !gave) res_slow_note(st, t0, nx, g, miss16, 2);
     }
     __syncthreads();
     if (wv == 0) {
@@ -1591,6 +1630,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
       const int o = t;
       const __amdgpu_buffer_rsrc_t rg = res_rsrc(gb, (size_t)nwg * RES_GSTRIDE * 8);
       unsigned pend = o < nwg ? (1u << (2 * NV)) - 1u : 0u;
+      int miss16 = -1;
       unsigned *svw = reinterpret_cast<unsigned *>(sval) + 2 * NV * o;
       unsigned seen = 0, rounds = 0;
       long long t0 = wall_clock64();
@@ -1616,6 +1656,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
           gave = true;
           break;
         }
+        if (rounds == 16u) { const unsigned long long ms = __ballot(pend != 0); miss16 = ms ? 64 * wv + (int)__ffsll((long long)ms) - 1 : -1; }
         if ((rounds & 63u) == 0 && wv == 0) {          // a long wait: say it again
           if (lane < 2 * NV) {
             const int i = lane >> 1;
@@ -1630,7 +1671,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
         if ((rounds & 255u) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __builtin_amdgcn_s_sleep(1);
       }
-      if (rounds >= 16u && lane == 0 && !gave) res_slow_note(st, t0);
+      if (rounds >= 16u && lane == 0 && !gave) res_slow_note(st, t0, nx, g, miss16, 2);
     }
     __syncthreads();
     if (wv == 0) {
@@ -1682,6 +1723,41 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
 }
 
 // ---------------------------------------------------------------------------
+// Elimination of slack-like variables from the linear system (launch-per-step kernels).
+//
+// A variable y that (1) appears in exactly ONE row i of A (coefficient a), (2) has no off-diagonal entry in P and
+// (3) shares its row with no other such variable couples to the rest of K = P + sigma I + A' rho A only through that row:
+//     K_yy = D_y = P_yy + sigma + rho_i a^2,     K_Xy = rho_i a A(i,X)'.
+// Eliminating all such y exactly (a block elimination with a DIAGONAL block) leaves, for the other variables X,
+//     S = P_XX + sigma I + A_X' diag(rho~) A_X,     rho~_i = rho_i (P_yy + sigma) / D_y   (rho~_i = rho_i on rows without a y),
+// i.e. the same operator with another weight on those rows; right-hand side b~_X = b_X - K_Xy b_y / D_y, back substitution
+// x~_y = (b_y - rho_i a (A_X x~_X)_i) / D_y.  Why it pays: on equality rows rho_i = 1e3 rho (include/constants.h:70), so K_yy
+// is huge against the Schur complement it hides and K is badly conditioned (Lasso, docs/examples/lasso.rst:41-63: the
+// residual variables y with y = Ad x - b; config 3 ran 98.6 PCG iterations per ADMM iteration); S has rho~ ~ P_yy + sigma
+// there.  Inertia: K > 0 <=> S > 0 and D > 0, so the convexity probe may run on the reduced operator too.
+// In the kernels: the PCG vectors are zero at the eliminated variables (k_pcg_init starts them so, k_cg_B keeps w_y = 0),
+// k_cg_A weighs rows with rho~ (Ctx::rhoe), k_admm_finalize back-substitutes and folds b_y into the m-part of the next
+// right-hand side.  The ADMM iterates themselves (x, z, y, residuals) never see any of this.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(TB) k_elim_refresh(Ctx c) {
+  const double sigma = c.prm->sigma;
+  for (int i = blockIdx.x * TB + threadIdx.x; i < c.m; i += gridDim.x * TB) {
+    const int y = c.ecol[i];
+    const double rho = c.rho[i];
+    if (y < 0) { c.rhoe[i] = rho; c.ecoef[i] = 0.0; c.edinv[i] = 0.0; continue; }
+    const double a = c.A.val[c.epos[i]], d0 = c.pdiag[y] + sigma, D = d0 + rho * a * a;
+    c.ecoef[i] = a; c.edinv[i] = 1.0 / D; c.rhoe[i] = rho * d0 / D;
+  }
+}
+// x~ of the eliminated variables lives in xte (per row), the PCG vectors are zero there: after the host wrote va's n-part
+__global__ void __launch_bounds__(TB) k_elim_split(Ctx c) {
+  for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
+    const int i = c.erow[j];
+    if (i >= 0) { c.xte[i] = c.va[j]; c.va[j] = 0.0; }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // auxiliary kernels
 // ---------------------------------------------------------------------------
 // Jacobi preconditioner: Minv_j = 1 / (P_jj + sigma + sum_i rho_i A_ij^2)
@@ -1691,21 +1767,33 @@ __global__ void __launch_bounds__(TB) k_precond(Ctx c) {
     double s = c.pdiag[j] + sigma;
     for (int k = c.M.split[j]; k < c.M.rowptr[j + 1]; ++k) {
       const double a = c.M.val[k];
-      s += c.rho[c.M.col[k] - c.n] * a * a;
+      s += c.rhoe[c.M.col[k] - c.n] * a * a;
     }
+    if (c.nelim && c.erow[j] >= 0) s = 1.0;       // (not part of the PCG system)
     c.minv[j] = 1.0 / s;
     c.g4[j].m = 1.0 / s; c.g4[c.n + j].m = 1.0 / s;
   }
 }
 
-// m-parts of the PCG input vectors from (z, z~, y, rho); rhoinv from rho.
-__global__ void __launch_bounds__(TB) k_refresh_m(Ctx c) {
+// m-parts of the PCG input vectors from (z, z~, y, rho); rhoinv from rho.  zt_partial: zt holds A x~ WITHOUT the
+// eliminated variables' terms (it was just recomputed from the PCG vector): complete it first.
+__global__ void __launch_bounds__(TB) k_refresh_m(Ctx c, int zt_partial) {
   const double *y = c.xy + c.n;
+  const Params prm = *c.prm;
   for (int i = blockIdx.x * TB + threadIdx.x; i < c.m; i += gridDim.x * TB) {
     const double rho = c.rho[i];
     c.rhoinv[i] = 1.0 / rho;
-    c.va[c.n + i] = rho * c.zt[i];
-    c.vb[c.n + i] = rho * c.z[i] - y[i];
+    const double vbn = rho * c.z[i] - y[i];
+    if (c.nelim && c.ecol[i] >= 0) {
+      const double a = c.ecoef[i], xt = c.xte[i];
+      double ax = c.zt[i];
+      if (zt_partial) c.zt[i] = ax + a * xt; else ax -= a * xt;
+      c.va[c.n + i] = c.rhoe[i] * ax;
+      c.vb[c.n + i] = elim_vb(c, prm, i, rho, vbn, c.xy[c.ecol[i]]);
+    } else {
+      c.va[c.n + i] = rho * c.zt[i];
+      c.vb[c.n + i] = vbn;
+    }
   }
 }
 
@@ -2067,9 +2155,11 @@ struct hipeng {
                              // kernels; the third in a row sends the engine there for good; a call without one starts the count again)
   long long res_gave_up = 0; // ... since create
   long long res_slow = 0, res_slow_max = 0, res_repub = 0;   // State::res_slow / res_slow_max / res_repub added up over the windows
+  long long res_slow_hist[4] = {0, 0, 0, 0}; unsigned res_slow_xcc = 0; int res_slow_last[4] = {0, 0, 0, 0};
   ResCtx rc{};
   BrCtx bc{};                // block-resident form (res_kind 2)
   int res_kind = 0;          // 0: launch-per-step only, 1: k_pcg_resident, 2: k_pcg_blockres
+  std::vector<int> erow, ecol, epos;   // host images of Ctx::erow / ecol / epos (empty: no variable is eliminated)
   size_t res_lds = 0;
   long long res_nnz = 0;
 };
@@ -2364,7 +2454,12 @@ static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr)
   if (!po) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, e->device));
-    nwg = std::min(256, prop.multiProcessorCount);
+    // One CU per XCD stays free.  A grid that takes EVERY CU can be preempted in mid-launch when anything else wants a CU:
+    // measured (profiles/r03_resident_slow_waits.txt) as waits of 1.05-1.10 ms, always the 32 workgroups of XCC 0 at once,
+    // about once per 20-30 s of 256-workgroup launches and never with a smaller grid -- the time it takes to save and
+    // restore an XCD's 32 x 570 KB of registers and LDS.  (Round 2's 1 ms wait limit turned each of them into a give-up.)
+    nwg = std::min(256, prop.multiProcessorCount) - 8;
+    if (const char *x = getenv("OSQP_AMD_RESIDENT_ALL_CUS")) if (atoi(x)) nwg += 8;
     if (prop.sharedMemPerBlock < 64 * 1024) RES_NO("too little LDS");
   }
   if (nwg <= 0 || nwg > 256 || (long long)nwg * RES_MAXROWS < n) RES_NO("too few CUs");
@@ -2626,6 +2721,7 @@ static int elem_grid(int cnt) {
 
 // Everything derived from (P, A, rho, sigma): the Jacobi preconditioner.
 static void refresh_operator(hipeng *e) {
+  if (e->c.nelim) hipLaunchKernelGGL(k_elim_refresh, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c);
   hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
   if (e->res_kind == 1) hipLaunchKernelGGL(k_form_K, dim3(std::min(2048, (e->n + 3) / 4)), dim3(TB), 0, e->stream, e->c, e->rc);
 }
@@ -2649,6 +2745,42 @@ static int push_params(hipeng *e) {
   HIPCHK(hipMemcpyAsync(e->d_prm, &e->prm, sizeof(Params), hipMemcpyHostToDevice, e->stream));
   // the source is host-pageable and may be reused right away
   HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+// Which variables can be eliminated from the linear system (see k_elim_refresh): exactly one entry in their column of A,
+// no off-diagonal entry in P, at most one such variable per row, the row not a huge one.  Launch-per-step engines only
+// (the resident forms hold K itself).  OSQP_AMD_ELIM=0 switches it off.
+static int build_elim(hipeng *e, const csc *P, const csc *A) {
+  Ctx &c = e->c;
+  c.nelim = 0; c.erow = c.ecol = c.epos = nullptr; c.rhoe = c.rho; c.ecoef = c.edinv = c.xte = nullptr;
+  const int n = e->n, m = e->m;
+  if (const char *x = getenv("OSQP_AMD_ELIM")) if (!atoi(x)) return 0;
+  if (e->res_on || m == 0 || n == 0) return 0;
+  std::vector<char> coupled(n, 0);
+  for (int j = 0; j < n; j++)
+    for (long long k = P->p[j]; k < P->p[j + 1]; k++) if (P->i[k] != j) { coupled[j] = 1; coupled[(int)P->i[k]] = 1; }
+  std::vector<int> erow(n, -1), ecol(m, -1), epos(m, 0);
+  int cnt = 0;
+  for (int j = 0; j < n; j++) {
+    if (coupled[j] || A->p[j + 1] - A->p[j] != 1) continue;
+    const long long k = A->p[j];
+    const int i = (int)A->i[k];
+    if (ecol[i] >= 0) continue;
+    if (e->A.rowptr[i + 1] - e->A.rowptr[i] >= HUGE_ROW) continue;
+    erow[j] = i; ecol[i] = j; epos[i] = e->A_csc2csr[k]; cnt++;
+  }
+  if (cnt == 0) return 0;
+  int *d_erow = nullptr, *d_ecol = nullptr, *d_epos = nullptr;
+  if (dev_alloc(e, &d_erow, (size_t)n) || dev_alloc(e, &d_ecol, (size_t)m) || dev_alloc(e, &d_epos, (size_t)m) ||
+      dev_alloc(e, &c.rhoe, (size_t)m) || dev_alloc(e, &c.ecoef, (size_t)m) || dev_alloc(e, &c.edinv, (size_t)m) || dev_alloc(e, &c.xte, (size_t)m)) return HIPENG_ERR_HIP;
+  HIPCHK(hipMemcpyAsync(d_erow, erow.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(d_ecol, ecol.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(d_epos, epos.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  c.erow = d_erow; c.ecol = d_ecol; c.epos = d_epos; c.nelim = cnt;
+  e->erow = erow; e->ecol = ecol; e->epos = epos;
+  if (e->trace) fprintf(stderr, "[osqp_amd] %d of %d variables eliminated from the linear system (one row of A each, no coupling in P)\n", cnt, n);
   return 0;
 }
 
@@ -2765,6 +2897,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   *out = e;
   if (int rc = build_blockres(e)) return rc;
   if (!e->res_on) { if (int rc = build_resident(e)) return rc; if (e->res_on) e->res_kind = 1; }
+  if (int rc = build_elim(e, P, A)) return rc;
   if (rho_vec) { int rc = hipeng_upload_rho(e, rho_vec); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
@@ -2896,7 +3029,8 @@ extern "C" int hipeng_upload_rho(hipeng *e, const c_float *rho_vec) {
   if (e->m > 0) {
     if (!rho_vec) return HIPENG_ERR_ARG;
     if (upload_vec(e, e->c.rho, rho_vec, e->m)) return HIPENG_ERR_HIP;
-    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
+    if (e->c.nelim) hipLaunchKernelGGL(k_elim_refresh, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c);
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c, 0); e->start_dirty = true;
   }
   refresh_operator(e);
   HIPCHK(hipGetLastError());
@@ -2931,7 +3065,7 @@ extern "C" int hipeng_upload_matrices(hipeng *e, const csc *P, const csc *A) {
   // z~ = A x~ for the new A so that the PCG warm start stays consistent
   if (e->m > 0) {
     hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, e->c.va, e->c.zt, 0);
-    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c, 1); e->start_dirty = true;
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -2947,7 +3081,7 @@ extern "C" int hipeng_matrices_changed(hipeng *e) {
   refresh_operator(e);
   if (e->m > 0) {
     hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, e->c.va, e->c.zt, 0);
-    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c, 1); e->start_dirty = true;
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -2963,6 +3097,7 @@ extern "C" int hipeng_cold_start(hipeng *e) {
   HIPCHK(hipMemsetAsync(e->c.vb, 0, std::max<size_t>(nm, 8), e->stream));
   HIPCHK(hipMemsetAsync(e->c.z, 0, std::max<size_t>(e->m, 1) * sizeof(double), e->stream));
   HIPCHK(hipMemsetAsync(e->c.zt, 0, std::max<size_t>(e->m, 1) * sizeof(double), e->stream));
+  if (e->c.nelim) HIPCHK(hipMemsetAsync(e->c.xte, 0, (size_t)e->m * sizeof(double), e->stream));
   e->calibrated = false; e->spec_lo = 0;   // the first solve from zero needs far more PCG iterations than the steady state
   e->start_dirty = true;
   return 0;
@@ -2977,13 +3112,15 @@ extern "C" int hipeng_set_iterates(hipeng *e, const c_float *x, const c_float *y
     if (upload_vec(e, e->c.xy, x, n)) return HIPENG_ERR_HIP;
     // PCG warm start x~ = x ; z = A x ; z~ = z   (osqp_warm_start, osqp.c:960-963)
     HIPCHK(hipMemcpyAsync(e->c.va, e->c.xy, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    if (e->c.nelim) hipLaunchKernelGGL(k_elim_split, dim3(elem_grid(n)), dim3(TB), 0, e->stream, e->c);
     e->start_dirty = true;
     if (m > 0) {
       hipLaunchKernelGGL(k_spmv, dim3(std::min(MAX_PARTS, std::max(1, e->c.A.nblk))), dim3(TB), 0, e->stream, e->c.A, e->c.xy, e->c.z, 0);
       HIPCHK(hipMemcpyAsync(e->c.zt, e->c.z, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     }
   }
-  if (m > 0) hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
+  if (m > 0) hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c, 0);
+  e->start_dirty = true;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
@@ -2996,7 +3133,7 @@ extern "C" int hipeng_set_z(hipeng *e, const c_float *z) {
   if (m > 0 && z) {
     if (upload_vec(e, e->c.z, z, m)) return HIPENG_ERR_HIP;
     HIPCHK(hipMemcpyAsync(e->c.zt, e->c.z, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c, 0); e->start_dirty = true;
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -3195,8 +3332,12 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     if (lease.owns_lock()) lease.unlock();
     e->res_slow += s.res_slow; e->res_slow_max = std::max<long long>(e->res_slow_max, s.res_slow_max); e->res_repub += s.res_repub;
     if (s.res_slow || s.res_repub) {
-      if (e->trace) fprintf(stderr, "[osqp_amd] resident waits: %d took more than 50 us (longest %.1f us), %d re-publications\n", s.res_slow, s.res_slow_max * 0.01, s.res_repub);
-      HIPCHK(hipMemsetAsync(&e->c.st->res_slow, 0, 3 * sizeof(int), e->stream));
+      for (int k = 0; k < 4; k++) { e->res_slow_hist[k] += s.res_slow_hist[k]; e->res_slow_last[k] = s.res_slow_last[k]; }
+      e->res_slow_xcc |= s.res_slow_xcc;
+      if (e->trace) fprintf(stderr, "[osqp_amd] resident waits of this window: %d took more than 50 us (50-200 us: %d, 200-500: %d, 0.5-2 ms: %d, longer: %d; longest %.1f us; XCC mask 0x%02x; "
+                                    "latest: exchange %d, workgroup %d missed workgroup %d, wait %d), %d re-publications\n", s.res_slow, s.res_slow_hist[0], s.res_slow_hist[1], s.res_slow_hist[2],
+                            s.res_slow_hist[3], s.res_slow_max * 0.01, s.res_slow_xcc, s.res_slow_last[0], s.res_slow_last[1], s.res_slow_last[2], s.res_slow_last[3], s.res_repub);
+      HIPCHK(hipMemsetAsync(&e->c.st->res_slow, 0, 12 * sizeof(int), e->stream));
     }
     if (s.res_fail) { had_fail = true; if (resident_gave_up(e, s, !e->trace)) return HIPENG_ERR_HIP; }
     const long long done_now = s.admm_done - start;
@@ -3323,13 +3464,13 @@ extern "C" int hipeng_kkt_solve(hipeng *e, c_float *b) {
   // reduced right-hand side: cvec = b1, vb(m-part) = rho . b2 ; start from x~ = 0
   if (hipeng_cold_start(e)) return HIPENG_ERR_HIP;
   if (upload_vec(e, e->c.cvec, b, n)) return HIPENG_ERR_HIP;
+  e->prm.use_cvec = 1;                       // (before the m-parts are formed: an eliminated variable's b_y comes from cvec then)
+  if (push_params(e)) return HIPENG_ERR_HIP;
   if (m > 0) {
     // stage b2 in z, y = 0  =>  k_refresh_m writes vb = rho*z - y = rho.b2
     if (upload_vec(e, e->c.z, b + n, m)) return HIPENG_ERR_HIP;
-    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c); e->start_dirty = true;
+    hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(m)), dim3(TB), 0, e->stream, e->c, 0); e->start_dirty = true;
   }
-  e->prm.use_cvec = 1;
-  if (push_params(e)) return HIPENG_ERR_HIP;
   int rc = hipeng_run_admm(e, 1);
   e->prm.use_cvec = 0;
   if (push_params(e)) return HIPENG_ERR_HIP;
@@ -3482,6 +3623,8 @@ extern "C" long long hipeng_timeline(hipeng *e, unsigned long long *out, long lo
 
 // 1 if the vector update and the operator apply of k_cg_A run as two launches (A dominated by long rows)
 extern "C" int hipeng_is_split(hipeng *e) { return e && e->split ? 1 : 0; }
+extern "C" int hipeng_row_eliminated(hipeng *e, c_int i) { return e && !e->ecol.empty() && i >= 0 && i < (c_int)e->ecol.size() && e->ecol[(size_t)i] >= 0 ? 1 : 0; }
+extern "C" c_int hipeng_elim_count(hipeng *e) { return e ? e->c.nelim : 0; }
 
 // Resident PCG: out[0] structures built, [1] in use, [2] entries of K per thread, [3] workgroups, [4] nnz(K),
 // [5] LDS bytes per workgroup, [6] PCG iterations of the most recent linear solve, [7] pipelined phase switched off for this K,

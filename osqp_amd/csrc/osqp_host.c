@@ -693,7 +693,7 @@ c_int osqp_solve(OSQPWorkspace *w) {
   if (!w) { fprintf(stderr, "ERROR in osqp_solve: Workspace not initialized\n"); return OSQP_WORKSPACE_NOT_INIT_ERROR; }
   hip_pcg_solver *s = PCG(w);
   OSQPSettings *st = w->settings;
-  c_int exitflag = 0, iter = 0, can_check = 0, can_print = 0, timed_out = 0;
+  c_int exitflag = 0, iter = 0, can_check = 0, can_print = 0;
   const c_int with_obj = st->verbose;
 
   if (w->clear_update_time == 1) w->info->update_time = 0.0;
@@ -723,8 +723,10 @@ c_int osqp_solve(OSQPWorkspace *w) {
     /* Equality rows carry rho_eq = 1e3 rho (constants.h:70): ||b|| is then dominated by their terms and a stop
      * relative to ||b|| leaves the rest of x~ far less accurate (configs 3 and 5: x, y within 1e-4 of the direct
      * solve at 1e-10, within 1e-6 at 1e-12).  Such problems get a stop 1e3 times tighter. */
+    /* ... unless the engine has eliminated a slack-like variable through that row (engine.hip, k_elim_refresh): the row then
+     * enters the reduced system with rho~ = rho (P_yy + sigma) / (P_yy + sigma + rho a^2), not with 1e3 rho. */
     for (c_int i = 0; i < w->data->m; i++)
-      if (w->constr_type[i] == 1) { prm.pcg_eps_rel = HMAX(1e-13, 1e-3 * prm.pcg_eps_rel); break; }
+      if (w->constr_type[i] == 1 && !hipeng_row_eliminated(s->eng, i)) { prm.pcg_eps_rel = HMAX(1e-13, 1e-3 * prm.pcg_eps_rel); break; }
   }
   const c_int adaptive_pcg = s->opt.pcg_adaptive;
   const c_float strict_rel = prm.pcg_eps_rel;
@@ -755,7 +757,7 @@ c_int osqp_solve(OSQPWorkspace *w) {
       if (t >= st->time_limit) {
         put_status(w->info, OSQP_TIME_LIMIT_REACHED);
         if (st->verbose) printf("run time limit reached\n");
-        can_print = 0; can_check = 0; timed_out = 1;
+        can_print = 0; can_check = 0;
         break;
       }
     }
@@ -779,13 +781,15 @@ c_int osqp_solve(OSQPWorkspace *w) {
   }
 
   if (!can_check) {
-    /* the reference leaves its loop by `break` on a time limit and then reports iter - 1 (osqp.c:404, 545) */
-    if (!can_print && refresh_info(w, iter - timed_out, with_obj)) { exitflag = 1; goto done; }
+    /* On a time limit the reference breaks at the TOP of iteration k and reports k - 1 = the iterations it completed
+     * (osqp.c:404, 545).  Here the limit is polled after a window, so `iter` iterations are complete and x, y and the
+     * residuals belong to iterate `iter`: that is the count reported. */
+    if (!can_print && refresh_info(w, iter, with_obj)) { exitflag = 1; goto done; }
     if (st->verbose && !w->summary_printed) { print_line(w); w->summary_printed = 1; }
     decide_termination(w, 0);
   }
   if (!with_obj && solution_exists(w->info)) {
-    if (s->sc_iter != iter - timed_out && refresh_info(w, iter - timed_out, 0)) { exitflag = 1; goto done; }
+    if (s->sc_iter != iter && refresh_info(w, iter, 0)) { exitflag = 1; goto done; }
     w->info->obj_val = s->sc.obj_scaled * (st->scaling ? w->scaling->cinv : 1.0);
   }
   if (st->verbose && !w->summary_printed) { print_line(w); w->summary_printed = 1; }

@@ -51,15 +51,26 @@ def gather_batch_records(bs, per, world, coll_dev):
     device (gloo rehearsal) the packed records take one D2H copy first.  Returns the [world * per, n + m + 8] tensor."""
     import torch
     import torch.distributed as dist
-    torch.cuda.synchronize()          # the batch engine writes the arrays on its own stream
-    X, Y, I = (torch.as_tensor(a, device="cuda") for a in bs.device_arrays())
-    rec = torch.zeros((per, bs.n + bs.m + 8), dtype=torch.float64, device=X.device)
-    rec[:bs.B, :bs.n] = X
-    if bs.m:
-        rec[:bs.B, bs.n:bs.n + bs.m] = Y[:, :bs.m]
-    rec[:bs.B, bs.n + bs.m:] = I
-    if coll_dev.type != "cuda":
-        rec = rec.cpu()
+    if getattr(bs, "_many", None) is not None:
+        # members above the batch kernel's size (one single-QP engine each): the records are built from the host results
+        r = bs.results()
+        rec = torch.zeros((per, bs.n + bs.m + 8), dtype=torch.float64)
+        rec[:bs.B, :bs.n] = torch.from_numpy(np.ascontiguousarray(r.x))
+        if bs.m:
+            rec[:bs.B, bs.n:bs.n + bs.m] = torch.from_numpy(np.ascontiguousarray(r.y))
+        rec[:bs.B, bs.n + bs.m:] = torch.from_numpy(np.ascontiguousarray(r.info_raw))
+        if coll_dev.type == "cuda":
+            rec = rec.to(coll_dev)
+    else:
+        torch.cuda.synchronize()          # the batch engine writes the arrays on its own stream
+        X, Y, I = (torch.as_tensor(a, device="cuda") for a in bs.device_arrays())
+        rec = torch.zeros((per, bs.n + bs.m + 8), dtype=torch.float64, device=X.device)
+        rec[:bs.B, :bs.n] = X
+        if bs.m:
+            rec[:bs.B, bs.n:bs.n + bs.m] = Y[:, :bs.m]
+        rec[:bs.B, bs.n + bs.m:] = I
+        if coll_dev.type != "cuda":
+            rec = rec.cpu()
     out = torch.empty((world * per, rec.shape[1]), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, rec)
     return out

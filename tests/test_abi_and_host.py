@@ -215,6 +215,32 @@ def test_spawn_ranks_sets_env_and_relays_rank0(tmp_path):
     assert spawn_ranks(3, [sys.executable, str(child), str(tmp_path), "fail"], stdout=io.StringIO()) == 3
 
 
+def test_spawn_ranks_ends_the_siblings_of_a_rank_that_dies(tmp_path):
+    """One rank dies early (no device, a failed setup): the others would sit in their next collective until the backend
+    times out.  spawn_ranks terminates them and returns the dead rank's code -- within seconds, not minutes."""
+    import io, time
+    from osqp_amd.launch import spawn_ranks
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys, time\n"
+                     "r = int(os.environ['RANK'])\n"
+                     "if r == 1: sys.exit(5)\n"
+                     "time.sleep(120)\n")
+    t0 = time.time()
+    assert spawn_ranks(3, [sys.executable, str(child)], stdout=io.StringIO()) == 5
+    assert time.time() - t0 < 30
+
+
+def test_batch_members_above_the_kernel_size_have_no_device_image():
+    """BatchOSQP with n > 128 runs one single-QP engine per member: device_arrays() must say so instead of handing a NULL
+    handle to the C side (dist.gather_batch_records builds its records from the host results on that path)."""
+    from osqp_amd.batch import BatchOSQP
+    b = BatchOSQP.__new__(BatchOSQP)
+    b._many = [object()]; b._h = None
+    with pytest.raises(RuntimeError, match="one single-QP engine per member"):
+        b.device_arrays()
+    b._many = None
+
+
 def test_bench_spawns_before_touching_the_gpu():
     """bench.py must start its ranks before torch / the HIP library are imported in the parent (a process that
     initialised the GPU must not fork workers that use it)."""

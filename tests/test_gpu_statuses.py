@@ -111,8 +111,9 @@ def test_time_limit_takes_the_approximate_branch(gpu_lib, oracle_mod):
     """osqp.c:583-598: on OSQP_TIME_LIMIT_REACHED the approximate check runs.  Warm-started at a 1e-7 solution
     and asked for eps = 1e-9, the iterate after the first window (8 iterations; the time limit is polled
     between windows) has residuals between eps and 10 eps: the oracle stopped at max_iter = 8 says
-    `solved inaccurate` through the same approximate check, and so must the time-limited run, which reports
-    iter - 1 like the reference (osqp.c:404, 545).  Far from the optimum the status stays `run time limit reached`."""
+    `solved inaccurate` through the same approximate check, and so must the time-limited run, which reports the
+    iterations it completed -- like the reference, whose `iter - 1` after its break at the top of iteration k is that count
+    (osqp.c:404, 545).  Far from the optimum the status stays `run time limit reached`."""
     import osqp_amd
     from osqp_amd import abi
     from osqp_amd.problems import random_sparse_qp
@@ -126,12 +127,12 @@ def test_time_limit_takes_the_approximate_branch(gpu_lib, oracle_mod):
     s = osqp_amd.OSQP().setup(**pb, eps_abs=1e-9, eps_rel=1e-9, check_termination=0, time_limit=1e-6, max_iter=100000)
     s.warm_start(x=r0.x, y=r0.y)
     r = s.solve()
-    assert r.info.status_val == abi.OSQP_SOLVED_INACCURATE and r.info.iter == 7
+    assert r.info.status_val == abi.OSQP_SOLVED_INACCURATE and r.info.iter == 8 == ro.info.iter
     assert _rel(r.x, ro.x) < 1e-6 and _rel(r.y, ro.y) < 1e-6
     assert abs(r.info.pri_res - ro.info.pri_res) <= 1e-3 * ro.info.pri_res and abs(r.info.dua_res - ro.info.dua_res) <= 1e-3 * ro.info.dua_res
     s2 = osqp_amd.OSQP().setup(**pb, eps_abs=1e-9, eps_rel=1e-9, check_termination=0, time_limit=1e-6, max_iter=100000)
     r2 = s2.solve()
-    assert r2.info.status_val == abi.OSQP_TIME_LIMIT_REACHED and r2.info.iter == 7
+    assert r2.info.status_val == abi.OSQP_TIME_LIMIT_REACHED and r2.info.iter == 8
 
 
 def _indefinite_qp(n, m, neg, seed):
