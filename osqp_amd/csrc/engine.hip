@@ -1544,8 +1544,15 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
   __shared__ double tot[8];                  // totals; [7]: a wait timed out
   __shared__ double sval[256 * NV];          // every workgroup's scalars during the exchange
   State *st = c.st;
+  TL_MARK(c, 6);
   if (st->stalled || !st->run || st->res_fail) return;
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6, nwg = bc.nwg;
+#ifdef OSQP_AMD_TIMELINE
+  __shared__ long long btl[6 * 64];          // phase stamps of the first 64 iterations (workgroup 0)
+#define BTL(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && nx >= 1 && nx <= 64) btl[(nx - 1) * 6 + (k)] = wall_clock64(); } while (0)
+#else
+#define BTL(k) do { } while (0)
+#endif
   const Params prm = *c.prm;
   const unsigned ep0 = st->res_epoch;
   // the row of this thread pair: row rl of the workgroup's (at most two) blocks, columns [64 h, 64 h + 64) of its block
@@ -1603,12 +1610,14 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
     ++nx;
     const unsigned tag = ep0 + (unsigned)nx;
     const int par = (int)(tag & 1u);
+    BTL(0);
     if (own) ul[rl] = u_;
     __syncthreads();
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 64; ++k) acc += kv[k] * ul[cb + h * 64 + k];
     acc += dpp_move<0xB1>(acc);                      // the two halves of the row
+    BTL(1);
     double v[NV];
     v[0] = own ? r_ * u_ : 0.0; v[1] = own ? acc * u_ : 0.0; v[2] = own ? r_ * r_ : 0.0;
 #pragma unroll
@@ -1616,6 +1625,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) { const double w_ = wave_sum(v[i]); if (lane == 0) red[wv * 8 + i] = w_; }
     __syncthreads();
+    BTL(2);
     unsigned long long *gb = reinterpret_cast<unsigned long long *>(bc.sbuf) + (size_t)par * nwg * RES_GSTRIDE;
     if (wv == 0 && lane < 2 * NV) {
       const int i = lane >> 1;
@@ -1673,6 +1683,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
       }
       if (rounds >= 16u && lane == 0 && !gave) res_slow_note(st, t0, nx, g, miss16, 2);
     }
+    BTL(3);
     __syncthreads();
     if (wv == 0) {
 #pragma unroll
@@ -1685,6 +1696,7 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
       }
     }
     __syncthreads();
+    BTL(4);
     if (tot[7] != 0.0) { failed = true; break; }
     const double gam = tot[0], rr = tot[2];
     double del = tot[1];
@@ -1703,7 +1715,18 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
       r_ -= cs.alpha * s_;
       u_ = mi * r_;
     }
+    BTL(5);
   }
+#ifdef OSQP_AMD_TIMELINE
+  if (g == 0 && t == 0 && !failed) {
+    const int cnt = (nx - 1 < 64 ? nx - 1 : 64) * 6;          // (the last trip broke out before its stamp 5)
+    const unsigned long long k0 = atomicAdd(c.tl, (unsigned long long)cnt + 1);
+    if (k0 + cnt + 1 < TL_CAP - 2) {
+      for (int q = 0; q < cnt; ++q) c.tl[1 + k0 + q] = ((unsigned long long)(40 + q % 6) << 56) | ((unsigned long long)btl[q] & 0x00FFFFFFFFFFFFFFull);
+      c.tl[1 + k0 + cnt] = (46ull << 56) | (wall_clock64() & 0x00FFFFFFFFFFFFFFull);
+    }
+  }
+#endif
   if (failed) {
     if (t == 0) {
       __hip_atomic_store(&st->res_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3477,7 +3500,13 @@ extern "C" int hipeng_kkt_solve(hipeng *e, c_float *b) {
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(b, e->c.va, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   if (m > 0) HIPCHK(hipMemcpyAsync(b + n, e->c.zt, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  std::vector<double> xte;
+  if (e->c.nelim) {          // x~ of the eliminated variables comes from the back substitution (the PCG vector is zero there)
+    xte.resize((size_t)m);
+    HIPCHK(hipMemcpyAsync(xte.data(), e->c.xte, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  }
   HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->c.nelim) for (int j = 0; j < n; j++) if (e->erow[(size_t)j] >= 0) b[j] = xte[(size_t)e->erow[(size_t)j]];
   return 0;
 }
 

@@ -29,3 +29,23 @@ for name in which:
         us = C.c_double(); by = C.c_double()
         L.hipeng_time_kernel(s.engine(), k, 100, C.byref(us)); L.hipeng_kernel_bytes(s.engine(), k, C.byref(by))
         print("   %s: %.1f us, %.1f MB -> %.0f GB/s" % (nm, us.value, by.value / 1e6, by.value / us.value / 1e3))
+    if hasattr(L, "hipeng_timeline") and st.get("resident") and name == "portfolio":     # make TIMELINE=1: phases of k_pcg_blockres, workgroup 0
+        L.hipeng_timeline.restype = C.c_longlong; L.hipeng_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
+        buf = np.zeros(1 << 20, dtype=np.uint64)
+        L.hipeng_timeline(s.engine(), buf.ctypes.data, buf.size)
+        s.update_settings(max_iter=200); s.solve(); s.update_settings(max_iter=4000)
+        k = L.hipeng_timeline(s.engine(), buf.ctypes.data, buf.size)
+        ids = (buf[:k] >> np.uint64(56)).astype(int); ts = (buf[:k] & np.uint64((1 << 56) - 1)).astype(np.int64) * 10e-3
+        sel = (ids >= 40) & (ids <= 46)
+        ii, tt = ids[sel], ts[sel]
+        names = {40: "iteration top", 41: "product done", 42: "partials in LDS", 43: "granules in", 44: "totals", 45: "update done", 46: "kernel end"}
+        nxt = {}
+        for a, b, d in zip(ii[:-1], ii[1:], np.diff(tt)):
+            if 0 <= d < 1e4: nxt.setdefault((a, b), []).append(d)
+        for (a, b), v in sorted(nxt.items()):
+            v = np.array(v)
+            print("   %-16s -> %-16s %6d x mean %6.2f us (median %5.2f, p90 %5.2f, max %6.2f)" % (names[a], names[b], v.size, v.mean(), np.median(v), np.percentile(v, 90), v.max()))
+        o = np.argsort(ts, kind="stable"); ids2, ts2 = ids[o], ts[o]
+        for a, b, nm in ((1, 6, "k_pcg_init start -> k_pcg_blockres start"), (46, 4, "k_pcg_blockres end -> k_admm_finalize start"), (4, 1, "k_admm_finalize start -> k_pcg_init start")):
+            v = np.array([d for x, y, d in zip(ids2[:-1], ids2[1:], np.diff(ts2)) if x == a and y == b and d < 1e4])
+            if v.size: print("   %-48s %6d x mean %6.2f us (median %5.2f)" % (nm, v.size, v.mean(), np.median(v)))
