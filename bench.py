@@ -202,7 +202,7 @@ def other_configs(eps):
                 L.hipeng_time_kernel(s.engine(), 5, 50, C.byref(t_init))
                 us_l = t_pair.value - t_init.value
                 out[name]["pcg_kernels_note"] = "launch-per-step kernels, timed for reference; the solve above used resident launches"
-                out[name]["resident_launch"] = dict(form="k_pcg_blockres" if info[9] == 2 else "k_pcg_resident", usec=round(us_l, 1),
+                out[name]["resident_launch"] = dict(form={2: "k_pcg_blockres", 3: "k_blk_apply + k_blk_finish (block-direct)"}.get(int(info[9]), "k_pcg_resident"), usec=round(us_l, 1),
                                                     pcg_iterations=int(info[6]), usec_per_pcg_iteration=round(us_l / max(1, int(info[6])), 2),
                                                     bytes_read_once_per_launch_MB=round((s.nnzP * 2 - s.n) * 8 / 1e6, 1) if info[9] == 2 else None)
         if name.startswith("config3"):

@@ -1746,6 +1746,122 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_blockres(Ctx c, BrCtx bc) {
 }
 
 // ---------------------------------------------------------------------------
+// Block-direct solve: the portfolio family (BASELINE config 5) without any iteration at all.
+//
+// Same structure as k_pcg_blockres accepts: P = dense diagonal blocks only, every row of A single-entry except nh <= 4
+// huge rows.  Then  K = B + A_h' R_h A_h  with B = blockdiag(P_b + sigma I + diag(sum_i rho_i a_ij^2)) and the nh huge
+// rows as a low-rank term, and by the Woodbury identity
+//     K^-1 r = t - W c,     t = B^-1 r,   W = B^-1 A_h' (n x nh),   c = (R_h^-1 + A_h W)^-1 (A_h t).
+// The blocks are inverted explicitly (k_blk_invert: in-place Gauss-Jordan in LDS, no pivoting -- B_b is positive
+// definite or the problem is not convex: a non-positive pivot is reported as negative curvature) whenever rho, sigma or
+// the matrices change, and kept in HBM in the layout of the dense blocks of P.  One linear solve is then
+//     k_blk_apply   t = B^-1 r0 : ONE pass over the 50 MB of inverse blocks (the dense_block_mv of k_cg_B, which the PCG
+//                   ran 26 times per ADMM iteration) + the partials of A_h t
+//     k_blk_finish  c from the partials (nh x nh system, inverted on the host at refresh), x~ = x~0 + t - W c
+// applied to the residual r0 = b - K x~0 of the warm start k_pcg_init forms anyway (one step of iterative refinement
+// on top of the previous x~: the error of the explicit inverse, ~cond(B) eps, multiplies the CORRECTION, not x~).
+// Config 5: 258 -> 4x us per ADMM iteration.  OSQP_AMD_BLOCK_DIRECT=0 keeps the block-resident PCG.
+// ---------------------------------------------------------------------------
+struct BdCtx {
+  double *binv;            // inverse blocks, layout of Ctx::dP.val (DenseBlk::off / pitch)
+  double *t;               // [n] B^-1 r
+  double *wh;              // [nh][n] W = B^-1 A_h'
+  double *cinv;            // [nh][nh] (R_h^-1 + A_h W)^-1
+  double *part;            // [MAX_HUGE_FOLD][nblk] partials of A_h t per block
+  int    *flag;            // [0] a pivot was not positive
+};
+
+__global__ void __launch_bounds__(TB) k_blk_invert(Ctx c, BdCtx bd) {
+  extern __shared__ __attribute__((aligned(16))) double bl[];       // b x b, row pitch b
+  __shared__ double colp[DENSE_MAX], rowp[DENSE_MAX];
+  __shared__ double pivs;
+  const double sigma = c.prm->sigma;
+  const int t = threadIdx.x;
+  for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
+    const DenseBlk d = c.dP.blk[db];
+    const int b = d.b;
+    for (int q = t; q < b * b; q += TB) { const int i = q / b, j = q % b; bl[q] = c.dP.val[d.off + (size_t)i * d.pitch + j]; }
+    __syncthreads();
+    if (t < b) {                       // diagonal: sigma + the single-entry rows of A at this column (the huge rows are the low-rank part)
+      const int j = d.c0 + t;
+      double dadd = sigma;
+      for (int k = c.Mk.rowptr[j]; k < c.Mk.rowptr[j + 1]; ++k) { const double a = c.Mk.val[k]; dadd += c.rho[c.Mk.col[k] - c.n] * a * a; }
+      bl[t * b + t] += dadd;
+    }
+    __syncthreads();
+    for (int p = 0; p < b; ++p) {
+      if (t < b) { colp[t] = bl[t * b + p]; rowp[t] = bl[p * b + t]; }
+      if (t == 0) pivs = bl[p * b + p];
+      __syncthreads();
+      const double piv = pivs;
+      if (!(piv > 0.0) && t == 0) atomicOr(bd.flag, 1);
+      const double inv = 1.0 / piv;
+      for (int q = t; q < b * b; q += TB) {
+        const int i = q / b, j = q % b;
+        double v;
+        if (i == p) v = (j == p) ? inv : rowp[j] * inv;
+        else if (j == p) v = -colp[i] * inv;
+        else v = bl[q] - colp[i] * rowp[j] * inv;
+        bl[q] = v;
+      }
+      __syncthreads();
+    }
+    for (int q = t; q < b * d.pitch; q += TB) { const int i = q / d.pitch, j = q % d.pitch; bd.binv[d.off + q] = j < b ? bl[i * b + j] : 0.0; }
+    __syncthreads();
+  }
+}
+
+// out_b = Binv_b in_b for every block (in, out contiguous n-vectors), and the partials of A_h out for the huge rows
+__global__ void __launch_bounds__(TB) k_blk_apply(Ctx c, BdCtx bd, const double *in, double *out, int gated) {
+  if (gated) { const State *st = c.st; if (st->stalled || !st->run) return; }
+  __shared__ double scratch[5 * DENSE_MAX];
+  __shared__ double red[16];
+  const DenseP inv{c.dP.nblk, c.dP.blk, bd.binv};
+  for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
+    const DenseBlk d = c.dP.blk[db];
+    const double y = dense_block_mv(inv, d, in, scratch);
+    const int j = d.c0 + threadIdx.x;
+    const bool on = (int)threadIdx.x < d.b;
+    if (on) out[j] = y;
+    for (int h = 0; h < c.nh; ++h) {
+      const double s = block_sum(on ? c.hcol[(size_t)h * c.n + j] * y : 0.0, red);
+      if (threadIdx.x == 0) bd.part[(size_t)h * c.dP.nblk + db] = s;
+    }
+    __syncthreads();
+  }
+}
+
+// x~ = x~0 + t - W c with c = Cinv (A_h t); the linear solve is complete (one "PCG iteration" in the statistics)
+__global__ void __launch_bounds__(TB) k_blk_finish(Ctx c, BdCtx bd) {
+  State *st = c.st;
+  if (st->stalled || !st->run) return;
+  __shared__ double red[16];
+  __shared__ double cs[MAX_HUGE_FOLD];
+  double sh[MAX_HUGE_FOLD];
+#pragma unroll
+  for (int h = 0; h < MAX_HUGE_FOLD; ++h) {
+    double s = 0.0;
+    if (h < c.nh) for (int i = threadIdx.x; i < c.dP.nblk; i += TB) s += bd.part[(size_t)h * c.dP.nblk + i];
+    sh[h] = h < c.nh ? block_sum(s, red) : 0.0;
+  }
+  if (threadIdx.x < MAX_HUGE_FOLD) {
+    double v = 0.0;
+    for (int h = 0; h < c.nh; ++h) v += bd.cinv[threadIdx.x * MAX_HUGE_FOLD + h] * sh[h];
+    cs[threadIdx.x] = (int)threadIdx.x < c.nh ? v : 0.0;
+  }
+  __syncthreads();
+  for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
+    double v = bd.t[j];
+    for (int h = 0; h < c.nh; ++h) v -= bd.wh[(size_t)h * c.n + j] * cs[h];
+    c.va[j] = c.vx[j] + v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->iters[0] = 1; st->iters[1] = 0; st->done = 1;
+    if (*bd.flag) st->neg_curv = 1;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Elimination of slack-like variables from the linear system (launch-per-step kernels).
 //
 // A variable y that (1) appears in exactly ONE row i of A (coefficient a), (2) has no off-diagonal entry in P and
@@ -2181,7 +2297,9 @@ struct hipeng {
   long long res_slow_hist[4] = {0, 0, 0, 0}; unsigned res_slow_xcc = 0; int res_slow_last[4] = {0, 0, 0, 0};
   ResCtx rc{};
   BrCtx bc{};                // block-resident form (res_kind 2)
-  int res_kind = 0;          // 0: launch-per-step only, 1: k_pcg_resident, 2: k_pcg_blockres
+  int res_kind = 0;          // 0: launch-per-step only, 1: k_pcg_resident, 2: k_pcg_blockres, 3: block-direct solve (k_blk_apply / k_blk_finish)
+  BdCtx bd{};                // block-direct form (res_kind 3)
+  std::vector<double> h_rho; // host copy of rho (the capacitance matrix of the block-direct form needs the huge rows' entries)
   std::vector<int> erow, ecol, epos;   // host images of Ctx::erow / ecol / epos (empty: no variable is eliminated)
   size_t res_lds = 0;
   long long res_nnz = 0;
@@ -2433,6 +2551,12 @@ template <int E> static int res_set_lds(size_t lds) {
   return 0;
 }
 static void launch_resident(hipeng *e) {
+  if (e->res_kind == 3) {
+    const int gb = std::max(1, std::min(1024, e->c.dP.nblk));
+    hipLaunchKernelGGL(k_blk_apply, dim3(gb), dim3(TB), 0, e->stream, e->c, e->bd, (const double *)e->c.init_r, e->bd.t, 1);
+    hipLaunchKernelGGL(k_blk_finish, dim3(std::max(1, std::min(256, (e->n + TB - 1) / TB))), dim3(TB), 0, e->stream, e->c, e->bd);
+    return;
+  }
   if (e->res_kind == 2) {
     const dim3 g2(e->bc.nwg), b2(RES_TB);
     switch (e->c.nh) {
@@ -2690,6 +2814,79 @@ static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr)
 }
 
 
+// Block-direct form (k_blk_invert / k_blk_apply / k_blk_finish): same eligibility as the block-resident PCG.
+static bool blocks_eligible(hipeng *e) {
+  if (e->dP_blks.empty()) return false;
+  int next = 0;
+  for (const DenseBlk &d : e->dP_blks) { if (d.c0 != next || d.b > DENSE_MAX) return false; next += d.b; }
+  if (next != e->n) return false;
+  // rows of A: one entry each, except the folded huge rows (all of the huge ones must be folded)
+  if ((int)e->A.blk.size() - e->A.nwave != (int)e->hrows.size()) return false;
+  std::vector<char> ishuge(std::max(1, e->m), 0);
+  for (int hr : e->hrows) ishuge[hr] = 1;
+  for (int i = 0; i < e->m; i++) if (!ishuge[i] && e->A.rowptr[i + 1] - e->A.rowptr[i] != 1) return false;
+  return true;
+}
+static int build_blockdirect(hipeng *e) {
+  int want = 1;
+  if (const char *x = getenv("OSQP_AMD_RESIDENT")) want = atoi(x);
+  if (const char *x = getenv("OSQP_AMD_RESIDENT_BLOCKS")) want = want && atoi(x);
+  if (const char *x = getenv("OSQP_AMD_BLOCK_DIRECT")) want = want && atoi(x);
+  if (!want || !blocks_eligible(e)) return 0;
+  BdCtx bd{};
+  const size_t nd = e->dP_src.size(), n = (size_t)e->n, nb = e->dP_blks.size();
+  if (dev_alloc(e, &bd.binv, nd) || dev_alloc(e, &bd.t, n) || dev_alloc(e, &bd.wh, (size_t)MAX_HUGE_FOLD * n) ||
+      dev_alloc(e, &bd.cinv, (size_t)MAX_HUGE_FOLD * MAX_HUGE_FOLD) || dev_alloc(e, &bd.part, (size_t)MAX_HUGE_FOLD * nb) || dev_alloc(e, &bd.flag, 4)) return HIPENG_ERR_HIP;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk_invert), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_MAX * DENSE_MAX * (int)sizeof(double)) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;                        // not an error: the block-resident PCG takes over
+  }
+  e->bd = bd;
+  // the solve kernels read the residual as a plain n-vector
+  e->c.init_r = e->c.r; e->c.init_stride = 1;
+  e->res_kind = 3; e->res_on = e->res_use = true;
+  if (e->trace) fprintf(stderr, "[osqp_amd] block-direct solve: %zu dense blocks inverted explicitly, %d huge rows of A as a Woodbury term\n", nb, (int)e->hrows.size());
+  return 0;
+}
+// New rho, sigma or matrix values: invert the blocks again, W = B^-1 A_h', capacitance matrix R_h^-1 + A_h W and its inverse.
+static int blk_refresh(hipeng *e) {
+  const Ctx &c = e->c;
+  const int nh = c.nh, nb = c.dP.nblk, n = e->n;
+  HIPCHK(hipMemsetAsync(e->bd.flag, 0, 4 * sizeof(int), e->stream));
+  int bmax = 1;
+  for (const DenseBlk &d : e->dP_blks) bmax = std::max(bmax, d.b);
+  hipLaunchKernelGGL(k_blk_invert, dim3(std::min(nb, 1024)), dim3(TB), (size_t)bmax * bmax * sizeof(double), e->stream, e->c, e->bd);
+  std::vector<double> C((size_t)MAX_HUGE_FOLD * MAX_HUGE_FOLD, 0.0), part((size_t)MAX_HUGE_FOLD * nb);
+  for (int h = 0; h < nh; h++) {
+    hipLaunchKernelGGL(k_blk_apply, dim3(std::min(nb, 1024)), dim3(TB), 0, e->stream, e->c, e->bd, (const double *)(c.hcol + (size_t)h * n), e->bd.wh + (size_t)h * n, 0);
+    HIPCHK(hipMemcpyAsync(part.data(), e->bd.part, part.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int h2 = 0; h2 < nh; h2++) { double s = 0.0; for (int q = 0; q < nb; q++) s += part[(size_t)h2 * nb + q]; C[(size_t)h2 * MAX_HUGE_FOLD + h] = s; }   // (A_h2 W_h)
+  }
+  HIPCHK(hipGetLastError());
+  bool bad = false;
+  for (int h = 0; h < nh; h++) {
+    const double rho = e->h_rho.size() > (size_t)c.hrow[h] ? e->h_rho[(size_t)c.hrow[h]] : 0.0;
+    if (!(rho > 0.0)) bad = true; else C[(size_t)h * MAX_HUGE_FOLD + h] += 1.0 / rho;
+  }
+  // inverse of the nh x nh capacitance matrix (symmetric positive definite when K is): Gauss-Jordan on the host
+  std::vector<double> I((size_t)MAX_HUGE_FOLD * MAX_HUGE_FOLD, 0.0);
+  for (int h = 0; h < nh; h++) I[(size_t)h * MAX_HUGE_FOLD + h] = 1.0;
+  for (int p = 0; p < nh && !bad; p++) {
+    const double piv = C[(size_t)p * MAX_HUGE_FOLD + p];
+    if (!(piv > 0.0)) { bad = true; break; }
+    for (int j = 0; j < nh; j++) { C[(size_t)p * MAX_HUGE_FOLD + j] /= piv; I[(size_t)p * MAX_HUGE_FOLD + j] /= piv; }
+    for (int i = 0; i < nh; i++) if (i != p) {
+      const double f = C[(size_t)i * MAX_HUGE_FOLD + p];
+      for (int j = 0; j < nh; j++) { C[(size_t)i * MAX_HUGE_FOLD + j] -= f * C[(size_t)p * MAX_HUGE_FOLD + j]; I[(size_t)i * MAX_HUGE_FOLD + j] -= f * I[(size_t)p * MAX_HUGE_FOLD + j]; }
+    }
+  }
+  if (bad) { const int one = 1; for (double &v : I) v = 0.0; HIPCHK(hipMemcpyAsync(e->bd.flag, &one, sizeof(int), hipMemcpyHostToDevice, e->stream)); }
+  HIPCHK(hipMemcpyAsync(e->bd.cinv, I.data(), I.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
 // Block-resident form (k_pcg_blockres): P = dense diagonal blocks only, rows of A single-entry or folded huge rows.
 static int build_blockres(hipeng *e) {
   const int n = e->n;
@@ -2708,7 +2905,7 @@ static int build_blockres(hipeng *e) {
   for (int i = 0; i < e->m; i++) if (!ishuge[i] && e->A.rowptr[i + 1] - e->A.rowptr[i] != 1) return 0;
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, e->device));
-  const int nwg = std::min(256, prop.multiProcessorCount);
+  const int nwg = std::min(256, prop.multiProcessorCount) - 8;       // one CU per XCD stays free (see build_resident)
   const int nb = (int)e->dP_blks.size();
   if (nb > 2 * nwg) RES_NO("more than two dense blocks per CU");
   // contiguous blocks, at most two and at most 256 rows per workgroup, spread evenly
@@ -2747,6 +2944,7 @@ static void refresh_operator(hipeng *e) {
   if (e->c.nelim) hipLaunchKernelGGL(k_elim_refresh, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c);
   hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
   if (e->res_kind == 1) hipLaunchKernelGGL(k_form_K, dim3(std::min(2048, (e->n + 3) / 4)), dim3(TB), 0, e->stream, e->c, e->rc);
+  if (e->res_kind == 3 && blk_refresh(e)) fprintf(stderr, "osqp_amd: the block-direct solve could not be refreshed\n");
 }
 
 // The PCG start vector history is void (cold/warm start from the host, new rho, new matrices):
@@ -2918,7 +3116,8 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
       upload_vec(e, c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
   e->stats.kernels_per_pcg_iter = 2;
   *out = e;
-  if (int rc = build_blockres(e)) return rc;
+  if (int rc = build_blockdirect(e)) return rc;
+  if (!e->res_on) if (int rc = build_blockres(e)) return rc;
   if (!e->res_on) { if (int rc = build_resident(e)) return rc; if (e->res_on) e->res_kind = 1; }
   if (int rc = build_elim(e, P, A)) return rc;
   if (rho_vec) { int rc = hipeng_upload_rho(e, rho_vec); if (rc) return rc; }
@@ -3052,6 +3251,7 @@ extern "C" int hipeng_upload_rho(hipeng *e, const c_float *rho_vec) {
   if (e->m > 0) {
     if (!rho_vec) return HIPENG_ERR_ARG;
     if (upload_vec(e, e->c.rho, rho_vec, e->m)) return HIPENG_ERR_HIP;
+    e->h_rho.assign(rho_vec, rho_vec + e->m);
     if (e->c.nelim) hipLaunchKernelGGL(k_elim_refresh, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c);
     hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c, 0); e->start_dirty = true;
   }
@@ -3338,7 +3538,7 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     // different engines of this process on one device take turns.  (Across processes there is no such lock: a
     // launch that finds CUs taken times out and the engine falls back, see k_pcg_resident.)
     std::unique_lock<std::mutex> lease;
-    if (resident) lease = std::unique_lock<std::mutex>(g_res_mu[e->device & 15]);
+    if (resident && e->res_kind != 3) lease = std::unique_lock<std::mutex>(g_res_mu[e->device & 15]);
     const long long burst = std::min<long long>(remaining, (e->calibrated || resident) ? 128 : 2);
     TR2(e, "launch burst=%lld K=%d", burst, e->K);
     // `burst` ADMM iterations = burst / segs graphs of `segs` segments + single-segment graphs for the rest
@@ -3563,7 +3763,7 @@ extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) 
   if (which == 8 && !(e->res_on && e->res_fails < 3)) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   std::unique_lock<std::mutex> lease;
-  if (which == 8) lease = std::unique_lock<std::mutex>(g_res_mu[e->device & 15]);
+  if (which == 8 && e->res_kind != 3) lease = std::unique_lock<std::mutex>(g_res_mu[e->device & 15]);
   auto one = [&](int it) {
     // the first two kernels of a resident ADMM iteration: right-hand side + start residual, then the whole linear solve
     // (without k_admm_finalize the iterates do not move: every repetition solves the same system from the same start)
@@ -3668,6 +3868,7 @@ extern "C" int hipeng_resident_info(hipeng *e, long long out[16]) {
   out[6] = std::max(s.iters[0], s.iters[1]); out[7] = s.res_pipe_off; out[8] = s.res_chk_fail; out[9] = e->res_kind; out[10] = e->res_gave_up; out[11] = e->res_slow + s.res_slow;
   out[12] = std::max<long long>(e->res_slow_max, s.res_slow_max); out[13] = e->res_repub + s.res_repub; out[14] = e->res_fails; out[15] = 0;
   if (e->res_kind == 2) { out[2] = 64; out[3] = e->bc.nwg; out[4] = 0; out[5] = 0; }
+  if (e->res_kind == 3) { out[2] = 0; out[3] = e->c.dP.nblk; out[4] = 0; out[5] = 0; }
   return 0;
 }
 

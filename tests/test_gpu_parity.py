@@ -419,7 +419,7 @@ def test_full_size_config3_config5_match_oracle_golden(gpu_lib, cfg):
     assert np.abs(r.x[::step] - xs).max() <= 1e-6 * max(1.0, g["x_inf"])
     assert np.abs(r.y[::step] - ys).max() <= 1e-6 * max(1.0, g["y_inf"])
     assert s.stats()["pcg_forced"] == 0
-    # config 5 runs its linear solves as block-resident launches (k_pcg_blockres), config 3 fits no resident form
+    # config 5 runs its linear solves as block-direct solves (k_blk_apply / k_blk_finish), config 3 fits no resident form
     assert s.stats()["resident"] == (1 if cfg == "config5" else 0)
 
 

@@ -169,31 +169,62 @@ def test_resident_with_many_entries_per_thread(gpu_lib, oracle_mod):
     assert _info(sg)["in_use"]
 
 
-def test_block_resident_portfolio_matches_oracle(gpu_lib, oracle_mod):
-    """k_pcg_blockres (P = dense diagonal blocks, rows of A single-entry + one huge budget row): 72 blocks of 125, the
-    budget row has 9000 entries.  Same trajectory as the oracle's direct solve; then new q and a warm-started solve; and the
-    same problem on the launch-per-step kernels (OSQP_AMD_RESIDENT_BLOCKS=0): one trajectory, two linear solvers."""
+@pytest.mark.parametrize("direct", [1, 0])
+def test_block_forms_of_the_portfolio_match_oracle(gpu_lib, oracle_mod, direct):
+    """P = dense diagonal blocks, rows of A single-entry + one huge budget row (72 blocks of 125, the budget row has 9000
+    entries).  direct=1: the block-direct solve (k_blk_invert / k_blk_apply / k_blk_finish: explicit inverse blocks + the budget
+    row as a Woodbury term, ONE "PCG iteration" per linear solve); direct=0: the block-resident PCG (k_pcg_blockres).  Same
+    trajectory as the oracle's direct solve; then new q and a warm-started solve, an osqp_update_rho; and the same problem on
+    the launch-per-step kernels (OSQP_AMD_RESIDENT_BLOCKS=0): one trajectory, three linear solvers."""
     import osqp_amd
     from osqp_amd.problems import portfolio_qp
     pb = portfolio_qp(72, 125, seed=5)
     kw = dict(eps_abs=1e-4, eps_rel=1e-4)
-    sg = osqp_amd.OSQP().setup(**pb, **kw); so = oracle_mod.OracleOSQP().setup(**pb, **kw)
+    with _env(OSQP_AMD_BLOCK_DIRECT=direct):
+        sg = osqp_amd.OSQP().setup(**pb, **kw)
+    so = oracle_mod.OracleOSQP().setup(**pb, **kw)
     inf = _info(sg)
-    assert inf["built"] and inf["form"] == 2, inf
+    assert inf["built"] and inf["form"] == (3 if direct else 2), inf
     rg, ro = sg.solve(), so.solve()
     assert rg.info.status == ro.info.status == "solved"
     assert rg.info.iter == ro.info.iter and rg.info.rho_updates == ro.info.rho_updates
     assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
     assert abs(rg.info.obj_val - ro.info.obj_val) <= 1e-6 * max(1.0, abs(ro.info.obj_val))     # (the bar of the full-size config-5 test)
+    if direct:
+        st = sg.stats()
+        assert st["pcg_iters_total"] == rg.info.iter and st["pcg_forced"] == 0          # one application of K^-1 per ADMM iteration
     q2 = pb["q"] * 0.9
     sg.update(q=q2); so.update(q=q2)
     rg2, ro2 = sg.solve(), so.solve()
     assert rg2.info.iter == ro2.info.iter and _rel(rg2.x, ro2.x) < 1e-6 and _rel(rg2.y, ro2.y) < 1e-6
+    sg.update_rho(0.4); so.update_rho(0.4)           # the inverse blocks and the capacitance matrix are formed again
+    rg3, ro3 = sg.solve(), so.solve()
+    assert rg3.info.iter == ro3.info.iter and _rel(rg3.x, ro3.x) < 1e-6 and _rel(rg3.y, ro3.y) < 1e-6
     with _env(OSQP_AMD_RESIDENT_BLOCKS=0):
         s2 = osqp_amd.OSQP().setup(**pb, **kw)
-    assert _info(s2)["form"] != 2
+    assert _info(s2)["form"] not in (2, 3)
     r2 = s2.solve()
     assert r2.info.iter == rg.info.iter and _rel(r2.x, rg.x) < 1e-7 and _rel(r2.y, rg.y) < 1e-7
+    assert _info(sg)["gave_up"] == 0
+
+
+def test_block_direct_reports_an_indefinite_block(gpu_lib):
+    """A dense block of P with a negative eigenvalue: the Gauss-Jordan inversion meets a non-positive pivot, the setup-time
+    convexity probe sees it as negative curvature and osqp_setup returns OSQP_NONCVX_ERROR (reference: the LDL' inertia test,
+    qdldl_interface.c:93-99)."""
+    import osqp_amd
+    from osqp_amd.problems import portfolio_qp
+    pb = portfolio_qp(72, 125, seed=2)
+    P = sparse.csc_matrix(pb["P"] + sparse.triu(pb["P"], 1).T).tolil()
+    w, V = np.linalg.eigh(P[:125, :125].toarray())
+    w[0] = -0.5
+    P[:125, :125] = (V * w) @ V.T
+    P = sparse.csc_matrix(P); P = ((P + P.T) * 0.5)
+    pb2 = dict(pb, P=sparse.triu(P, format="csc"))
+    ok = osqp_amd.OSQP().setup(**{k: pb[k] for k in "PqAlu"})
+    assert _info(ok)["form"] == 3
+    with pytest.raises(ValueError, match="error 5"):
+        osqp_amd.OSQP().setup(**{k: pb2[k] for k in "PqAlu"})
 
 
 def test_a_launch_that_gives_up_costs_one_window(gpu_lib, oracle_mod):
