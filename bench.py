@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-inexact", action="store_true", help="skip the opt-in inexact-mode leg (shorter traces under rocprofv3)")
     ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / config 5 legs")
     ap.add_argument("--cpu-batch-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-single-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     return ap.parse_args()
 
@@ -250,12 +251,24 @@ def _recorded(cfg):
         return None
 
 
-def cpu_baseline(n, eps):
-    """Oracle = CPU checker; here it is the timed baseline, never the product path."""
+def cpu_single_worker(spec):
+    """The single-QP CPU baseline, run in a child process on ONE core while the parent drives the GPU legs (prints one JSON
+    object).  Oracle = CPU checker; here it is the timed baseline, never the product path.
+      (1) the benchmarked instance itself (n, m of the headline): per-phase times of the direct path's setup
+          (qdldl_interface.c:177-323: KKT assembly, ordering, permutation + elimination tree, numeric factorisation); the
+          numeric phase takes minutes single-threaded, so it runs for a bounded time with its flops counted and is
+          extrapolated by the exact flop count (oracle/orc_ldl.c, orc_ldl_phase_times);
+      (2) the same recipe at the bounded sample size, whole solves: the reported `value`."""
+    n, m, cpu_n, eps, budget = spec.split(",")
+    n, m, cpu_n, eps, budget = int(n), int(m), int(cpu_n), float(eps), float(budget)
     import oracle.oracle as orc
+    from osqp_amd import _abi as abi
     from osqp_amd.problems import random_sparse_qp
+    from scipy import sparse
     orc.build()
-    pb = random_sparse_qp(n, 2 * n, seed=1)
+    out = {}
+    # ---- (2) bounded sample, whole solves ----
+    pb = random_sparse_qp(cpu_n, 2 * cpu_n, seed=1)
     t0 = time.perf_counter()
     s = orc.OracleOSQP().setup(**pb, eps_abs=eps, eps_rel=eps, adaptive_rho_interval=100, warm_start=0)
     t_setup = time.perf_counter() - t0
@@ -267,13 +280,102 @@ def cpu_baseline(n, eps):
         t_solve += time.perf_counter() - t0
         iters += r.info.iter
         runs += 1
-    return dict(value=round(iters / t_solve, 2), unit="ADMM iters/s", cores=1, kind="port",
-                sample="same recipe at n=%d, m=%d (direct LDL^T fill grows ~quadratically; the full "
-                       "n=10000 factorisation alone takes minutes single-threaded, see DESIGN.md); "
-                       "%d solves, each osqp_update_rho(0.1) + cold-started osqp_solve (so the in-solve rho update "
-                       "and its re-factorisation are included, as on the GPU); setup (ordering+factor) %.2fs excluded"
-                       % (n, 2 * n, runs, t_setup),
-                setup_s=round(t_setup, 3), host_cpus=os.cpu_count(), recorded_full_size=_recorded("config2"))
+    L = orc.lib()
+    L.orc_linsys_nnzL.restype = C.c_longlong; L.orc_linsys_nnzL.argtypes = [C.c_void_p]
+    nnzL_s = int(L.orc_linsys_nnzL(C.cast(s.work.linsys_solver, C.c_void_p)))
+    # seconds per ADMM iteration of the sample without its refactorisations: rho updates excluded by timing iterations alone
+    t0 = time.perf_counter(); s.iterate(20); t_iter_s = (time.perf_counter() - t0) / 20
+    out["sample"] = dict(n=cpu_n, m=2 * cpu_n, iters=iters, solve_s=t_solve, runs=runs, setup_s=t_setup, nnzL=nnzL_s, iter_s=t_iter_s)
+    # ---- (1) the benchmarked instance ----
+    pb = random_sparse_qp(n, m, seed=1)
+    f = L.orc_ldl_phase_times
+    f.restype = C.c_longlong
+    f.argtypes = [C.POINTER(abi.csc), C.POINTER(abi.csc), C.c_double, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]
+    Pu = abi.CscHolder(sparse.triu(pb["P"], format="csc")); Ah = abi.CscHolder(pb["A"])
+    rho = np.full(m, RHO0); o = (C.c_double * 8)()
+    if f(C.byref(Pu.struct), C.byref(Ah.struct), 1e-6, rho.ctypes.data_as(C.POINTER(C.c_double)), budget, o) == 0:
+        out["phases"] = dict(form_kkt_s=o[0], ordering_s=o[1], symbolic_s=o[2], nnzL=int(o[3]), numeric_flops=o[4],
+                             numeric_flops_done=o[5], numeric_s_spent=o[6], numeric_finished=bool(o[7]))
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_start(a):
+    """Start the single-QP CPU baseline in a child process (before anything in this process touches the GPU)."""
+    import subprocess
+    spec = "%d,%d,%d,%g,%g" % (a.n, a.m, a.cpu_n, a.eps, 20.0)
+    return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-single-worker", spec], stdout=subprocess.PIPE, text=True)
+
+
+def cpu_baseline_join(proc, cpu_n):
+    try:
+        txt = proc.communicate(timeout=240)[0]
+        d = json.loads(txt.strip().splitlines()[-1])
+    except Exception as ex:                      # the leg is a reported baseline: its failure must not cost the bench line
+        try: proc.kill()
+        except Exception: pass
+        return dict(value=None, unit="ADMM iters/s", cores=1, kind="port", sample="the CPU baseline child failed: %r" % (ex,))
+    sm = d["sample"]
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count()
+    out = dict(value=round(sm["iters"] / sm["solve_s"], 2), unit="ADMM iters/s", cores=1, kind="port",
+               sample="same recipe at n=%d, m=%d (the direct factorisation of the benchmarked n=10000 instance alone takes minutes on one "
+                      "core: see benchmarked_instance); %d solves, each osqp_update_rho(0.1) + cold-started osqp_solve (so the in-solve rho "
+                      "update and its re-factorisation are included, as on the GPU); setup (ordering + factor) %.2f s excluded; timed in a "
+                      "child process on one core of this host while the GPU legs ran" % (sm["n"], sm["m"], sm["runs"], sm["setup_s"]),
+               setup_s=round(sm["setup_s"], 3), host_cpus=os.cpu_count(), host_cpus_usable=avail, recorded_full_size=_recorded("config2"))
+    ph = d.get("phases")
+    if ph:
+        rate = ph["numeric_flops_done"] / max(ph["numeric_s_spent"], 1e-9)
+        num_s = ph["numeric_s_spent"] if ph["numeric_finished"] else ph["numeric_flops"] / max(rate, 1.0)
+        iter_s = sm["iter_s"] * ph["nnzL"] / max(sm["nnzL"], 1)          # triangular solves are linear in nnz(L)
+        # one step of the benchmark on this instance: 125 iterations and one re-factorisation (the rho update at iteration 100)
+        est = 125.0 / (125.0 * iter_s + num_s)
+        out["benchmarked_instance"] = dict(
+            n=None, form_kkt_s=round(ph["form_kkt_s"], 3), ordering_s=round(ph["ordering_s"], 2), symbolic_s=round(ph["symbolic_s"], 2), nnzL=ph["nnzL"],
+            numeric_gflop=round(ph["numeric_flops"] / 1e9, 1), numeric_gflops_rate_measured=round(rate / 1e9, 2),
+            numeric_fraction_measured=round(ph["numeric_flops_done"] / max(ph["numeric_flops"], 1.0), 4), numeric_s_measured=round(ph["numeric_s_spent"], 1),
+            numeric_s_extrapolated=round(num_s, 1), iteration_s_extrapolated=round(iter_s, 3), admm_iters_per_s_estimated=round(est, 3),
+            note="measured on this host, one core, on the benchmarked instance: assembly, ordering and elimination tree run to the end; the numeric "
+                 "factorisation ran for the stated seconds with its flops counted and is extrapolated by the exact flop count sum Lnz (Lnz - 1) "
+                 "(an optimistic figure: the first rows have the shortest columns); a solve iteration is extrapolated from the sample by nnz(L); "
+                 "estimate = 125 iterations / (125 iteration times + one re-factorisation), the step the GPU is timed on; recorded_full_size is the "
+                 "complete run of the same instance in the build container")
+        out["benchmarked_instance"].pop("n")
+    return out
+
+
+def rowpart_config5(dist, rank, world, dev_id, eps):
+    """BASELINE config 5 "1 -> N MI355X": ONE portfolio QP whose rows of A and blocks of P are sharded over the N ranks
+    (osqp_amd/rowpart.py: one n-vector all-reduce per PCG iteration), next to the same QP on one GPU (rank 0).  Only run
+    with N > 1.  Status per DESIGN.md section 7: bound by all-reduce latency; it cannot beat one GPU's block-direct solve
+    at this size -- the leg exists so that a multi-GPU node measures that curve instead of leaving it to an estimate."""
+    import torch
+    from osqp_amd import rowpart
+    from osqp_amd.problems import portfolio_qp
+    import osqp_amd
+    pb = portfolio_qp()
+    kw = dict(eps_abs=eps, eps_rel=eps, adaptive_rho_interval=100)
+    scaled = rowpart.scaled_problem_from_engine(**pb, device=dev_id)
+    rp = rowpart.RowPartitionedOSQP().setup(scaled, rowpart.HipOps, device=dev_id, **kw)
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = rp.solve()
+    torch.cuda.synchronize(); dist.barrier()
+    dt = time.perf_counter() - t0
+    out = None
+    if rank == 0:
+        s1 = osqp_amd.OSQP().setup(**pb, **kw, warm_start=0)
+        s1.solve()
+        t1 = time.perf_counter(); r1 = s1.solve(); d1 = time.perf_counter() - t1
+        out = dict(workload="config5 portfolio n=50000 (400 dense blocks of 125), ONE QP row-partitioned over %d ranks" % world,
+                   status=r.info.status, admm_iters=int(r.info.iter), solve_s=round(dt, 4), admm_iters_per_s=round(r.info.iter / dt, 1),
+                   pcg_iters=int(r.info.pcg_iters), collectives=int(r.info.collectives),
+                   single_gpu=dict(status=r1.info.status, admm_iters=int(r1.info.iter), admm_iters_per_s=round(r1.info.iter / d1, 1)),
+                   note="rows of A and blocks of P sharded, n-vectors replicated, one n-vector all-reduce per PCG iteration; the single-GPU figure "
+                        "is the block-direct solve (DESIGN.md 2b)")
+    return out
 
 
 def bench_batch(batch, dist, rank, local_rank, world, coll_dev, steps=10, with_cpu=True):
@@ -384,8 +486,8 @@ def bench_batch(batch, dist, rank, local_rank, world, coll_dev, steps=10, with_c
             avail = len(os.sched_getaffinity(0))
         except Exception:
             avail = os.cpu_count() or 1
-        nw = max(1, min(64, avail))
-        per_w = max(1, nb // nw)
+        nw = max(1, min(256, avail, batch))            # every core this job may use, one worker process each
+        per_w = max(1, min(batch, 1024) // nw)
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-batch-worker",
                                    "%d,%d,%g" % (w * per_w, (w + 1) * per_w, 5.0)], stdout=subprocess.PIPE, text=True)
                  for w in range(nw)]
@@ -420,6 +522,8 @@ def main():
     a = parse()
     if a.cpu_batch_worker:
         return cpu_batch_worker(a.cpu_batch_worker)
+    if a.cpu_single_worker:
+        return cpu_single_worker(a.cpu_single_worker)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not started by a launcher: start one process per GPU ourselves (before anything touches the GPU)
         # and relay rank 0's JSON line; the children see WORLD_SIZE and take the branch below
@@ -430,6 +534,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != max(1, a.gpus) and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d: running %d rank(s)" % (a.gpus, world, world), file=sys.stderr)
+    cpu_child = None
+    if world == 1 and rank == 0 and not a.no_cpu:
+        cpu_child = cpu_baseline_start(a)          # one core, beside the GPU legs; joined before the CPU legs of the batch
     import torch
     dist = None
     ndev = max(1, torch.cuda.device_count())
@@ -485,6 +592,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     pcg_total = solver.stats()["pcg_iters_total"]
+    L_ = osqp_amd.lib()
+    L_.hipeng_resident_info.restype = C.c_int; L_.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    res_buf = (C.c_longlong * 16)(); L_.hipeng_resident_info(solver.engine(), res_buf)
+    res_info = [int(v) for v in res_buf]      # [10] launches that gave up, [11] waits over 50 us, [12] the longest (ticks of 10 ns)
 
     tot_iters, max_t = float(iters), elapsed
     if dist is not None:
@@ -495,8 +606,14 @@ def main():
         max_t, tot_iters = float(t.item()), float(it.item())
 
     batch = None
-    if a.batch:
-        batch = bench_batch(a.batch, dist, rank, dev_id, world, coll_dev, with_cpu=not a.no_cpu)
+    if a.batch and world > 1:
+        batch = bench_batch(a.batch, dist, rank, dev_id, world, coll_dev, with_cpu=False)
+    rowpart5 = None
+    if world > 1 and not a.no_configs:
+        try:
+            rowpart5 = rowpart_config5(dist, rank, world, dev_id, a.eps)
+        except Exception as ex:                      # a reported side leg: it must not cost the headline line
+            rowpart5 = dict(error=repr(ex)) if rank == 0 else None
 
     if rank == 0:
         st = solver.stats()
@@ -513,6 +630,7 @@ def main():
                        "rho_updates_per_solve": int(last.info.rho_updates) - ru_prev if a.steps > 1 else None,
                        "pcg_iters_per_admm_iter": round(pcg_total / max(1, (a.steps + a.warmup) * last.info.iter), 2),
                        "graph_launches": st["graph_launches"], "host_syncs": st["host_syncs"],
+                       "resident_gave_up": res_info[10], "resident_slow_waits": res_info[11], "resident_slow_wait_max_us": round(res_info[12] * 0.01, 1),
                        "linear_solves": ("resident launches (K = P + sigma I + A' rho A in registers, one launch per solve)" if st.get("resident")
                                          else "launch-per-step PCG kernels (k_cg_A, k_cg_B)"),
                        "parallelism": "replicas x%d (a single QP does not shard)" % world},
@@ -534,8 +652,12 @@ def main():
             out["roofline"] = kernel_roofline(solver)
             if not a.no_configs:
                 out["other_configs"] = other_configs(a.eps)
-            if not a.no_cpu:
-                out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.eps)
+            if cpu_child is not None:
+                out["cpu_baseline"] = cpu_baseline_join(cpu_child, a.cpu_n)
+            if a.batch:                       # (after the single-QP CPU child has finished: its CPU legs use every usable core)
+                batch = bench_batch(a.batch, dist, rank, dev_id, world, coll_dev, with_cpu=not a.no_cpu)
+        if rowpart5 is not None:
+            out["config5_row_partitioned"] = rowpart5
         if batch is not None:
             out["batch"] = batch
         print(json.dumps(out), flush=True)

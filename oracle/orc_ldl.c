@@ -472,3 +472,87 @@ fail:
   *sp = NULL;
   return rc;
 }
+
+/* ======================================================================== */
+/* Phase timings of init_linsys_solver with a time budget (bench.py only)    */
+/* ======================================================================== */
+/* What the direct path costs on ONE core for a problem whose factorisation takes minutes (the benchmarked config-2
+ * instance: qdldl_interface.c:177-323 = form_KKT + ordering + permutation + etree + numeric factor).  The phases up to
+ * the elimination tree run to the end; the numeric factorisation -- the same up-looking loop as orc_ldl_factor -- runs for
+ * at most `budget_s` seconds while its flops are counted, and is extrapolated by the EXACT flop count of the whole
+ * factorisation, sum_c Lnz_c (Lnz_c - 1) (each entry appended to column c follows a pass over the entries already there).
+ * out: [0] form_KKT s, [1] ordering s, [2] permutation + etree s, [3] nnz(L), [4] flops of the whole numeric phase,
+ *      [5] flops done, [6] seconds they took, [7] 1 = the numeric phase finished within the budget. */
+c_int orc_ldl_phase_times(const csc *P, const csc *A, c_float sigma, const c_float *rho_vec, c_float budget_s, c_float out[8]) {
+  const c_int n = P->n, m = A->m, N = n + m;
+  for (int k = 0; k < 8; k++) out[k] = 0.0;
+  c_float *rho_inv = (c_float *)malloc((size_t)(m > 0 ? m : 1) * sizeof(c_float));
+  c_int *perm = (c_int *)malloc((size_t)(N + 1) * sizeof(c_int)), *pinv = (c_int *)malloc((size_t)(N + 1) * sizeof(c_int));
+  c_int *etree = (c_int *)malloc((size_t)(N + 1) * sizeof(c_int)), *Lnz = (c_int *)malloc((size_t)(N + 1) * sizeof(c_int));
+  c_int *iwork = (c_int *)malloc((size_t)(3 * N + 3) * sizeof(c_int)), *Lp = (c_int *)malloc((size_t)(N + 2) * sizeof(c_int));
+  c_float *D = (c_float *)malloc((size_t)(N + 1) * sizeof(c_float)), *Dinv = (c_float *)malloc((size_t)(N + 1) * sizeof(c_float));
+  c_float *y = (c_float *)calloc((size_t)(N + 1), sizeof(c_float));
+  unsigned char *seen = (unsigned char *)calloc((size_t)(N + 1), 1);
+  csc *K0 = NULL, *K = NULL; c_int *KtoPK = NULL, *Li = NULL; c_float *Lx = NULL;
+  c_int rc = -1;
+  if (!rho_inv || !perm || !pinv || !etree || !Lnz || !iwork || !Lp || !D || !Dinv || !y || !seen) goto done;
+  for (c_int i = 0; i < m; i++) rho_inv[i] = 1. / rho_vec[i];
+  double t0 = orc_now();
+  K0 = orc_form_KKT(P, A, sigma, rho_inv, NULL, NULL, NULL);
+  if (!K0) goto done;
+  out[0] = orc_now() - t0; t0 = orc_now();
+  if (orc_min_degree_order(N, K0->p, K0->i, perm) < 0) goto done;
+  out[1] = orc_now() - t0; t0 = orc_now();
+  for (c_int k = 0; k < N; k++) pinv[perm[k]] = k;
+  KtoPK = (c_int *)malloc((size_t)(K0->p[N] + 1) * sizeof(c_int));
+  if (!KtoPK) goto done;
+  K = orc_symperm_triu(K0, pinv, KtoPK);
+  if (!K) goto done;
+  const c_int nnzL = orc_ldl_etree(N, K->p, K->i, iwork, Lnz, etree);
+  if (nnzL < 0) goto done;
+  out[2] = orc_now() - t0; out[3] = (c_float)nnzL;
+  double ftot = 0.0;
+  for (c_int c = 0; c < N; c++) ftot += (double)Lnz[c] * (double)(Lnz[c] > 0 ? Lnz[c] - 1 : 0);
+  out[4] = ftot;
+  Li = (c_int *)malloc((size_t)(nnzL + 1) * sizeof(c_int)); Lx = (c_float *)malloc((size_t)(nnzL + 1) * sizeof(c_float));
+  if (!Li || !Lx) goto done;
+  {
+    c_int *reach = iwork, *path = iwork + N, *fill = iwork + 2 * N;
+    const c_int *Ap = K->p, *Ai = K->i; const c_float *Ax = K->x;
+    Lp[0] = 0;
+    for (c_int j = 0; j < N; j++) { Lp[j + 1] = Lp[j] + Lnz[j]; D[j] = 0.0; fill[j] = Lp[j]; }
+    double fdone = 0.0; t0 = orc_now();
+    c_int k = 0;
+    for (; k < N; k++) {
+      if ((k & 63) == 0 && orc_now() - t0 > budget_s) break;
+      c_int nreach = 0;
+      for (c_int t = Ap[k]; t < Ap[k + 1]; t++) {
+        c_int i = Ai[t];
+        if (i == k) { D[k] = Ax[t]; continue; }
+        y[i] = Ax[t];
+        if (seen[i]) continue;
+        c_int plen = 0;
+        for (c_int v = i; v != -1 && v < k && !seen[v]; v = etree[v]) { seen[v] = 1; path[plen++] = v; }
+        while (plen) reach[nreach++] = path[--plen];
+      }
+      for (c_int t = nreach - 1; t >= 0; t--) {
+        c_int c = reach[t];
+        c_float yc = y[c];
+        c_int end = fill[c];
+        for (c_int q = Lp[c]; q < end; q++) y[Li[q]] -= Lx[q] * yc;
+        fdone += 2.0 * (double)(end - Lp[c]);
+        Li[end] = k; Lx[end] = yc * Dinv[c];
+        D[k] -= yc * Lx[end];
+        fill[c]++; y[c] = 0.0; seen[c] = 0;
+      }
+      if (D[k] == 0.0) break;
+      Dinv[k] = 1.0 / D[k];
+    }
+    out[5] = fdone; out[6] = orc_now() - t0; out[7] = k == N ? 1.0 : 0.0;
+  }
+  rc = 0;
+done:
+  free(rho_inv); free(perm); free(pinv); free(etree); free(Lnz); free(iwork); free(Lp); free(D); free(Dinv); free(y); free(seen);
+  free(KtoPK); free(Li); free(Lx); orc_csc_free(K0); orc_csc_free(K);
+  return rc;
+}

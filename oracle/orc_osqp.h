@@ -62,6 +62,8 @@ c_int orc_min_degree_order(c_int n, const c_int *Ap, const c_int *Ai, c_int *per
 c_int orc_init_linsys_solver(LinSysSolver **s, const csc *P, const csc *A,
                              c_float sigma, const c_float *rho_vec, c_int polish);
 c_int orc_linsys_nnzL(const LinSysSolver *s);
+/* bench.py: per-phase times of the direct path's setup with a time budget for the numeric factorisation (orc_ldl.c) */
+c_int orc_ldl_phase_times(const csc *P, const csc *A, c_float sigma, const c_float *rho_vec, c_float budget_s, c_float out[8]);
 
 /* ---- public API (src/osqp.c) -------------------------------------------- */
 void  orc_osqp_set_default_settings(OSQPSettings *settings);

@@ -103,6 +103,7 @@ typedef struct {
   hipeng_scalars sc;      /* last residual scalars                                */
   c_int sc_iter;          /* iteration they belong to (-1 = stale)                */
   c_int host_syncs;
+  c_int forced_warned;    /* the pcg_forced warning has been printed for this workspace */
   osqp_amd_options opt;   /* this instance's engine options (copied from the defaults at creation) */
 } hip_pcg_solver;
 
@@ -813,15 +814,21 @@ c_int osqp_solve(OSQPWorkspace *w) {
   if (w->first_run) w->first_run = 0;
   w->clear_update_time = 1;
   w->rho_update_from_solve = 0;
-  if (st->verbose) {
-    hipeng_stats hs;
+  if (st->verbose)
     printf("status: %s, iterations: %lld, objective: %.4f, run time: %.2es, rho estimate: %.2e\n",
            w->info->status, (long long)w->info->iter, w->info->obj_val, w->info->run_time,
            w->info->rho_estimate);
-    /* an indirect solve that hit its iteration cap (or broke down) was accepted as it stood: say so */
-    if (!hipeng_get_stats(s->eng, &hs) && hs.pcg_forced > 0)
-      printf("warning: %lld linear solve(s) stopped at the PCG iteration cap or on a breakdown before reaching the "
-             "requested accuracy (osqp_amd_get_stats: pcg_forced)\n", (long long)hs.pcg_forced);
+  {
+    /* An indirect solve that hit its iteration cap (or broke down) was accepted as it stood.  OSQPInfo is ABI and has no
+     * field for it, so: one line on stderr per workspace, whatever `verbose` says (every solve when verbose);
+     * osqp_amd_get_stats(work, &st) -> st.pcg_forced has the count.  The reference's direct solve has no such state. */
+    hipeng_stats hs;
+    if (!hipeng_get_stats(s->eng, &hs) && hs.pcg_forced > 0 && (st->verbose || !s->forced_warned)) {
+      s->forced_warned = 1;
+      fprintf(stderr, "osqp_amd warning: %lld linear solve(s) of this workspace so far stopped at the PCG iteration cap or on a breakdown "
+                      "before reaching the requested accuracy; the iterates were accepted as they stood (osqp_amd_get_stats: "
+                      "pcg_forced; OSQP_AMD_PCG_MAX_ITER raises the cap)\n", (long long)hs.pcg_forced);
+    }
   }
 done:
   return exitflag;

@@ -230,3 +230,21 @@ def test_wrapper_rejects_out_of_bounds_updates(gpu_lib):
     assert s.solve().info.status == "solved"
     with pytest.raises(ValueError):
         osqp_amd.BatchOSQP().setup(pb["P"], pb["A"], np.zeros((2, 60)), np.ones((2, 90)), np.zeros((2, 90)))   # l > u
+
+
+def test_a_capped_linear_solve_is_reported_without_verbose(gpu_lib):
+    """An indirect solve that stops at its iteration cap is accepted as it stands; OSQPInfo (ABI) cannot say so.  osqp_solve
+    therefore prints ONE warning per workspace on stderr even with verbose = 0, and osqp_amd_get_stats counts the solves."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import osqp_amd\n"
+            "from osqp_amd.problems import random_sparse_qp\n"
+            "osqp_amd.set_engine_options(pcg_max_iter=3)\n"
+            "s = osqp_amd.OSQP().setup(**random_sparse_qp(200, 400, seed=2), max_iter=50)\n"
+            "s.solve(); s.solve()\n"
+            "print('forced', s.stats()['pcg_forced'])\n") % root
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert int(p.stdout.split("forced")[1]) > 0
+    assert p.stderr.count("osqp_amd warning:") == 1 and "pcg_forced" in p.stderr
