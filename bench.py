@@ -100,18 +100,21 @@ def kernel_roofline(solver, reps=300):
         assert L.hipeng_time_kernel(solver.engine(), 5, reps2, C.byref(t_init)) == 0
         us = t_pair.value - t_init.value
         gbs = b_pcg * its / us / 1e3
-        traffic, src = None, "profiles/r02_config2_resident_pmc_and_durations.json"
+        traffic, src, stale = None, "profiles/r03_config2_pmc_and_durations.json", None
         try:
+            import hashlib
             prof = json.load(open(os.path.join(ROOT, src)))
             if (n, m) == (10000, 20000):
                 k = [v for kk, v in prof["kernels"].items() if kk.startswith("k_pcg_resident")][0]
                 traffic = float(k["traffic_bytes_corrected"])
+                now = hashlib.sha256(open(os.path.join(ROOT, "osqp_amd", "csrc", "engine.hip"), "rb").read()).hexdigest()
+                stale = prof.get("engine_hip_sha256") != now          # the PMC passes ran on another build of engine.hip
         except Exception:
             traffic = None
         return dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 5),
-                    traffic=traffic, kernel="k_pcg_resident",
+                    traffic=traffic, traffic_from_another_build=stale, kernel="k_pcg_resident",
                     traffic_note="HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes (%s); "
-                                 "the factor 2 on FETCH_SIZE is measured in profiles/r02_fetch_calibration.json" % src,
+                                 "the factor 2 on FETCH_SIZE is measured in profiles/r02_fetch_calibration.json; traffic_from_another_build says whether engine.hip has changed since those passes" % src,
                     bytes_per_launch=b_pcg * its, usec_per_launch=round(us, 3), pcg_iterations_per_launch=its,
                     usec_per_pcg_iteration=round(us / max(its, 1), 3),
                     resident=dict(nnzK=int(info[4]), workgroups=int(info[3]), entries_per_thread=int(info[2]), lds_bytes=int(info[5]),
@@ -134,7 +137,7 @@ def kernel_roofline(solver, reps=300):
     # (profiles/r02_fetch_calibration.json: FETCH_SIZE tallies 128-byte requests at 64 B)
     traffic, src = None, None
     try:
-        src = "profiles/r02_config2_pmc_and_durations.json"
+        src = "profiles/r03_config2_pmc_and_durations.json"
         prof = json.load(open(os.path.join(ROOT, src)))
         if (solver.n, solver.m) == (10000, 20000):
             k = [v for kk, v in prof["kernels"].items() if kk.startswith(dom["kernel"])][0]
@@ -144,7 +147,7 @@ def kernel_roofline(solver, reps=300):
     return dict(bound="hbm", achieved=round(dom["gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(dom["gbs"] / HBM_PEAK_GBS, 5), traffic=traffic, kernel=dom["kernel"],
                 traffic_note="HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes (%s); "
-                             "the factor 2 on FETCH_SIZE is measured in profiles/r02_fetch_calibration.json" % src,
+                             "the factor 2 on FETCH_SIZE is measured in profiles/r02_fetch_calibration.json; traffic_from_another_build says whether engine.hip has changed since those passes" % src,
                 bytes_per_launch=dom["bytes"], usec_per_launch=round(dom["usec"], 3),
                 note="launch-to-launch period of %d graph-captured back-to-back launches (includes the "
                      "dependent-kernel boundary); the 8 MB working set is L2/Infinity-Cache resident" % reps,
@@ -367,7 +370,7 @@ def rowpart_config5(dist, rank, world, dev_id, eps):
     out = None
     if rank == 0:
         s1 = osqp_amd.OSQP().setup(**pb, **kw, warm_start=0)
-        s1.solve()
+        s1.solve(); s1.update_rho(RHO0)
         t1 = time.perf_counter(); r1 = s1.solve(); d1 = time.perf_counter() - t1
         out = dict(workload="config5 portfolio n=50000 (400 dense blocks of 125), ONE QP row-partitioned over %d ranks" % world,
                    status=r.info.status, admm_iters=int(r.info.iter), solve_s=round(dt, 4), admm_iters_per_s=round(r.info.iter / dt, 1),
@@ -608,12 +611,23 @@ def main():
     batch = None
     if a.batch and world > 1:
         batch = bench_batch(a.batch, dist, rank, dev_id, world, coll_dev, with_cpu=False)
-    rowpart5 = None
+    rowpart5, wedged = None, False
     if world > 1 and not a.no_configs:
+        # a reported side leg: it must not cost the headline line.  A rank that fails or stalls in here leaves the others
+        # inside a collective, so every rank runs it under an alarm; after a failure the process group is not used again.
+        import signal
+
+        def _late(signum, frame):
+            raise TimeoutError("row-partitioned leg exceeded its 180 s")
+        signal.signal(signal.SIGALRM, _late)
+        signal.alarm(180)
         try:
             rowpart5 = rowpart_config5(dist, rank, world, dev_id, a.eps)
-        except Exception as ex:                      # a reported side leg: it must not cost the headline line
+        except BaseException as ex:
+            wedged = True
             rowpart5 = dict(error=repr(ex)) if rank == 0 else None
+        finally:
+            signal.alarm(0)
 
     if rank == 0:
         st = solver.stats()
@@ -661,6 +675,9 @@ def main():
         if batch is not None:
             out["batch"] = batch
         print(json.dumps(out), flush=True)
+    if wedged:
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -145,6 +145,10 @@ struct Ctx {             // static pointers / sizes, passed by value
   double *pdir, *ut;               // Chronopoulos-Gear PCG: p, [u|t]
   G4     *g4;                      // ... and {r, w, s, Minv} records, ping-ponged on parity (2n)
   int     init_stride;             // element stride of init_r (4 when it points into g4)
+  // resident PCG: k_pcg_init also leaves u0 = Minv r0 in the layout of the exchanged vector (position u0map[j] of u0pos), so that
+  // the resident launch takes it in with one coalesced sweep instead of a 2-byte-indexed gather (null: not a k_pcg_resident engine)
+  const unsigned short *u0map;
+  double *u0pos;
   // Slack-like variables eliminated from the linear system (k_elim_refresh): nelim = 0 switches all of it off (rhoe == rho then)
   int     nelim;
   const int *erow, *ecol, *epos;   // [n] row of an eliminated variable (-1: not eliminated); [m] the row's eliminated variable (-1: none), slot of that entry in A.val
@@ -435,6 +439,7 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c, int bench) {
       const double zj = c.minv[j] * rj;
       c.init_r[(size_t)j * c.init_stride] = rj;
       c.init_z[j] = zj;
+      if (c.u0pos) c.u0pos[c.u0map[j]] = zj;
       prz += rj * zj; prr += rj * rj; pbb += bj * bj;
     }
     __syncthreads();
@@ -467,6 +472,7 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c, int bench) {
         const double zj = c.minv[j] * rj;
         c.init_r[(size_t)j * c.init_stride] = rj;
         c.init_z[j] = zj;
+        if (c.u0pos) c.u0pos[c.u0map[j]] = zj;
         prz += rj * zj; prr += rj * rj; pbb += bj * bj;
       }
     }
@@ -1284,8 +1290,18 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
   // in the lanes of wavefront 0 (ends with the barrier that makes the segments visible)
   // u0 = Minv r0 was left in global memory by k_pcg_init (an earlier launch: plain loads see it): no exchange needed
   auto load_u0 = [&]() __attribute__((always_inline)) {
-#pragma unroll 4
-    for (int jj = t; jj < c.n; jj += RES_TB) uv[rc.rowpos[jj]] = c.init_z[jj];
+    // (k_pcg_init left it in the layout of the exchanged vector: one coalesced sweep, every load in flight at once)
+    const double2 *src = reinterpret_cast<const double2 *>(c.u0pos);
+    const int half = npad >> 1;
+#pragma unroll
+    for (int h8 = 0; h8 < RES_MAXLD; h8 += 4) {          // four loads in flight per thread and round (registers are the entries of K's)
+      if (h8 * RES_TB >= half) break;
+      double2 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int i2 = (h8 + q) * RES_TB + t; if (i2 < half) v[q] = src[i2]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int i2 = (h8 + q) * RES_TB + t; if (i2 < half) { uv[2 * i2] = v[q].x; uv[2 * i2 + 1] = v[q].y; } }
+    }
     __syncthreads();
   };
   auto products_issue = [&]() __attribute__((always_inline)) {
@@ -1774,39 +1790,42 @@ struct BdCtx {
 __global__ void __launch_bounds__(TB) k_blk_invert(Ctx c, BdCtx bd) {
   extern __shared__ __attribute__((aligned(16))) double bl[];       // b x b, row pitch b
   __shared__ double colp[DENSE_MAX], rowp[DENSE_MAX];
-  __shared__ double pivs;
   const double sigma = c.prm->sigma;
-  const int t = threadIdx.x;
+  // thread -> column j and the rows i = i0, i0 + 2, ... (no index arithmetic in the sweep: a division per element
+  // made this kernel 2.85 ms for the 400 blocks of config 5)
+  const int t = threadIdx.x, j = t & (DENSE_MAX - 1), i0 = t / DENSE_MAX;
+  static_assert(TB == 2 * DENSE_MAX, "two rows per sweep step");
   for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
     const DenseBlk d = c.dP.blk[db];
     const int b = d.b;
-    for (int q = t; q < b * b; q += TB) { const int i = q / b, j = q % b; bl[q] = c.dP.val[d.off + (size_t)i * d.pitch + j]; }
+    if (j < b) for (int i = i0; i < b; i += 2) bl[i * b + j] = c.dP.val[d.off + (size_t)i * d.pitch + j];
     __syncthreads();
     if (t < b) {                       // diagonal: sigma + the single-entry rows of A at this column (the huge rows are the low-rank part)
-      const int j = d.c0 + t;
+      const int jj = d.c0 + t;
       double dadd = sigma;
-      for (int k = c.Mk.rowptr[j]; k < c.Mk.rowptr[j + 1]; ++k) { const double a = c.Mk.val[k]; dadd += c.rho[c.Mk.col[k] - c.n] * a * a; }
+      for (int k = c.Mk.rowptr[jj]; k < c.Mk.rowptr[jj + 1]; ++k) { const double a = c.Mk.val[k]; dadd += c.rho[c.Mk.col[k] - c.n] * a * a; }
       bl[t * b + t] += dadd;
     }
     __syncthreads();
     for (int p = 0; p < b; ++p) {
       if (t < b) { colp[t] = bl[t * b + p]; rowp[t] = bl[p * b + t]; }
-      if (t == 0) pivs = bl[p * b + p];
       __syncthreads();
-      const double piv = pivs;
+      const double piv = rowp[p];
       if (!(piv > 0.0) && t == 0) atomicOr(bd.flag, 1);
       const double inv = 1.0 / piv;
-      for (int q = t; q < b * b; q += TB) {
-        const int i = q / b, j = q % b;
-        double v;
-        if (i == p) v = (j == p) ? inv : rowp[j] * inv;
-        else if (j == p) v = -colp[i] * inv;
-        else v = bl[q] - colp[i] * rowp[j] * inv;
-        bl[q] = v;
+      if (j < b) {
+        const double rj = rowp[j] * inv;              // row p of the result (j != p)
+        for (int i = i0; i < b; i += 2) {
+          double v;
+          if (i == p) v = (j == p) ? inv : rj;
+          else if (j == p) v = -colp[i] * inv;
+          else v = bl[i * b + j] - colp[i] * rj;
+          bl[i * b + j] = v;
+        }
       }
       __syncthreads();
     }
-    for (int q = t; q < b * d.pitch; q += TB) { const int i = q / d.pitch, j = q % d.pitch; bd.binv[d.off + q] = j < b ? bl[i * b + j] : 0.0; }
+    if (j < d.pitch) for (int i = i0; i < b; i += 2) bd.binv[d.off + (size_t)i * d.pitch + j] = j < b ? bl[i * b + j] : 0.0;
     __syncthreads();
   }
 }
@@ -2791,6 +2810,11 @@ static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr)
   UP(d_wg, wg); UP(d_rowpos, rowpos); UP(d_col, col); UP(d_rowl, rowl); UP(d_krp, Kptr); UP(d_kcj, Kcol); UP(d_kps, Kps); UP(d_kdst, kdst); UP(d_brk, brk); UP(d_slot0, slot0); UP(d_segrow, segrow);
 #undef UP
   HIPCHK(hipStreamSynchronize(e->stream));       // the sources are locals
+  {
+    double *d_u0pos = nullptr;
+    if (dev_alloc(e, &d_u0pos, (size_t)rc.npad)) return HIPENG_ERR_HIP;       // (zeroed: the padding positions are read, never written)
+    e->c.u0map = d_rowpos; e->c.u0pos = d_u0pos;
+  }
   rc.wg = d_wg; rc.rowpos = d_rowpos; rc.col = d_col; rc.rowl = d_rowl; rc.krp = d_krp; rc.kcj = d_kcj; rc.kps = d_kps; rc.kdst = d_kdst; rc.brk = d_brk; rc.slot0 = d_slot0; rc.segrow = d_segrow;
   e->rc = rc;
   e->res_lds = ((size_t)rc.npad + RES_TB + RES_MAXROWS + 3 + 16 + 768 + 5 * 64 + 48) * sizeof(double);   // + phase stamps of the TIMELINE build

@@ -57,6 +57,11 @@ def main():
         if "FETCH_SIZE_KB" in e and "WRITE_SIZE_KB" in e:
             e["traffic_bytes_corrected"] = round(1024.0 * (2.0 * e["FETCH_SIZE_KB"]["median"] + e["WRITE_SIZE_KB"]["median"]))
         res["kernels"][k] = e
+    # which build the passes ran on: bench.py flags a `traffic` figure taken from another build of the engine as stale
+    import hashlib, os
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "osqp_amd", "csrc", "engine.hip")
+    try: res["engine_hip_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    except OSError: res["engine_hip_sha256"] = None
     json.dump(res, open(outp, "w"), indent=1)
     for k, e in res["kernels"].items():
         print(k, {kk: (vv["median"] if isinstance(vv, dict) else vv) for kk, vv in e.items()})
