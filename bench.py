@@ -122,8 +122,8 @@ def kernel_roofline(solver, reps=300):
                                   register_bytes_of_K=int(info[4]) * 10,
                                   # what the launch moves on chip instead of streaming matrices: every CU reads the exchanged vector
                                   # (rows + riding partials, line-padded) once per PCG iteration
-                                  exchange_bytes_per_iteration=int(info[3]) * (int(info[5]) - 8 * (512 + 61 + 3 + 16 + 768 + 5 * 64 + 48)),
-                                  exchange_gbs_l2_to_cus=round(int(info[3]) * (int(info[5]) - 8 * (512 + 61 + 3 + 16 + 768 + 5 * 64 + 48)) * its / us / 1e3, 1)),
+                                  exchange_bytes_per_iteration=int(info[3]) * (int(info[5]) - 8 * (512 + 61 + 3 + 16 + 768 + 5 * 64 + 96)),
+                                  exchange_gbs_l2_to_cus=round(int(info[3]) * (int(info[5]) - 8 * (512 + 61 + 3 + 16 + 768 + 5 * 64 + 96)) * its / us / 1e3, 1)),
                     note="one launch = one linear solve: K = P + sigma I + A' rho A (%d entries) sits in the register files of %d CUs, "
                          "each PCG iteration exchanges one n-vector between the workgroups inside the launch; duration = (%d graph-captured "
                          "[k_pcg_init, k_pcg_resident] pairs - the same count of k_pcg_init) / %d, every repetition the same solve of %d PCG "

@@ -77,7 +77,7 @@ c_int init_linsys_solver(LinSysSolver **s, const csc *P, const csc *A, c_float s
  * defaults picked up by the next osqp_setup / init_linsys_solver_hip_pcg;
  * also settable through the environment:
  *   OSQP_AMD_PCG_EPS_REL (default 1e-9), OSQP_AMD_PCG_EPS_ABS (1e-15),
- *   OSQP_AMD_PCG_MAX_ITER (0 = max(1000, 2n... see DESIGN.md)), OSQP_AMD_DEVICE (0). */
+ *   OSQP_AMD_PCG_MAX_ITER (0 = max(20000, 10n): see DESIGN.md), OSQP_AMD_DEVICE (0). */
 typedef struct {
   c_float pcg_eps_rel;
   c_float pcg_eps_abs;

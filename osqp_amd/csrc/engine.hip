@@ -74,6 +74,8 @@ struct DevMat {
   int nwave;             // PCG kernels: long rows [nstream,nwave) take one wavefront each, [nwave,nblk) are huge
   const int    *rowptr;
   const int    *col;
+  const unsigned short *col16;   // the same column ids as 16-bit words where every id fits (null otherwise): the long-row passes
+                                 // stream 10 instead of 12 bytes per entry (config 3: 26 -> 22 us per pass over A)
   const double *val;
   const int    *split;   // M only: first entry of the A' part of each row
   const RowBlk *blk;
@@ -346,12 +348,22 @@ __device__ __forceinline__ double wave_row_dot(const DevMat &Mx, int ka, int kb,
   const int lane = threadIdx.x & 63;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int k = ka + lane;
-  for (; k + 192 < kb; k += 256) {
-    const int c0 = Mx.col[k], c1 = Mx.col[k + 64], c2 = Mx.col[k + 128], c3 = Mx.col[k + 192];
-    const double v0 = Mx.val[k], v1 = Mx.val[k + 64], v2 = Mx.val[k + 128], v3 = Mx.val[k + 192];
-    s0 += v0 * xval(c0); s1 += v1 * xval(c1); s2 += v2 * xval(c2); s3 += v3 * xval(c3);
+  if (Mx.col16) {
+    const unsigned short *c16 = Mx.col16;
+    for (; k + 192 < kb; k += 256) {
+      const int c0 = c16[k], c1 = c16[k + 64], c2 = c16[k + 128], c3 = c16[k + 192];
+      const double v0 = Mx.val[k], v1 = Mx.val[k + 64], v2 = Mx.val[k + 128], v3 = Mx.val[k + 192];
+      s0 += v0 * xval(c0); s1 += v1 * xval(c1); s2 += v2 * xval(c2); s3 += v3 * xval(c3);
+    }
+    for (; k < kb; k += 64) s0 += Mx.val[k] * xval((int)c16[k]);
+  } else {
+    for (; k + 192 < kb; k += 256) {
+      const int c0 = Mx.col[k], c1 = Mx.col[k + 64], c2 = Mx.col[k + 128], c3 = Mx.col[k + 192];
+      const double v0 = Mx.val[k], v1 = Mx.val[k + 64], v2 = Mx.val[k + 128], v3 = Mx.val[k + 192];
+      s0 += v0 * xval(c0); s1 += v1 * xval(c1); s2 += v2 * xval(c2); s3 += v3 * xval(c3);
+    }
+    for (; k < kb; k += 64) s0 += Mx.val[k] * xval(Mx.col[k]);
   }
-  for (; k < kb; k += 64) s0 += Mx.val[k] * xval(Mx.col[k]);
   return wave_sum((s0 + s1) + (s2 + s3));      // valid in lane 0
 }
 
@@ -444,39 +456,48 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c, int bench) {
     }
     __syncthreads();
   }
-  for (int bi = blockIdx.x; bi < Mm.nblk; bi += gridDim.x) {
+  // row j of the start-up given sA = (M [x~0 | rho z~0])_j and sB = (M [0 | rho z - y])_j, by one thread
+  auto row_start = [&](int j, double sA, double sB) {
+    if (DENSE) for (int k = 0; k < c.nh; ++k) { const double hc = c.hcol[(size_t)k * c.n + j]; sA += hc * c.vx[c.n + c.hrow[k]]; sB += hc * c.vb[c.n + c.hrow[k]]; }
+    const double base = prm.use_cvec ? c.cvec[j] : (prm.sigma * c.xy[j] - c.q[j]);
+    const bool gone = c.nelim && c.erow[j] >= 0;           // eliminated from the system: no residual, no direction
+    const double bj = gone ? 0.0 : base + sB;
+    const double rj = gone ? 0.0 : bj - prm.sigma * c.vx[j] - sA;
+    const double zj = c.minv[j] * rj;
+    c.init_r[(size_t)j * c.init_stride] = rj;
+    c.init_z[j] = zj;
+    if (c.u0pos) c.u0pos[c.u0map[j]] = zj;
+    prz += rj * zj; prr += rj * rj; pbb += bj * bj;
+  };
+  for (int bi = blockIdx.x; bi < Mm.nstream; bi += gridDim.x) {
     const RowBlk b = Mm.blk[bi];
-    const bool longrow = IS_LONG(b);
-    if (!longrow) {
-      stage_products<2>(Mm, b, c.vx, c.vb, lprod, lprod + MAX_CHUNK);
-      __syncthreads();
-    }
+    stage_products<2>(Mm, b, c.vx, c.vb, lprod, lprod + MAX_CHUNK);
+    __syncthreads();
     // the summation order is free here (PCG-internal): several lanes per row
-    const int RL = longrow ? 1 : lanes_for(b.r1 - b.r0), rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
-    for (int j = b.r0 + (longrow ? 0 : rg); j < b.r1; j += (longrow ? 1 : TB / RL)) {
-      double sA, sB;
-      if (longrow) {
-        sA = long_row_dot(Mm, b.k0, b.k1, c.vx, red);
-        sB = long_row_dot(Mm, b.k0, b.k1, c.vb, red);
-      } else {
-        const int a0 = Mm.rowptr[j] - b.k0, a1 = Mm.rowptr[j + 1] - b.k0;
-        sA = row_sum_par(lprod, a0, a1, rlane, RL);
-        sB = row_sum_par(lprod + MAX_CHUNK, a0, a1, rlane, RL);
-      }
-      if (longrow ? threadIdx.x == 0 : rlane == 0) {
-        if (DENSE) for (int k = 0; k < c.nh; ++k) { const double hc = c.hcol[(size_t)k * c.n + j]; sA += hc * c.vx[c.n + c.hrow[k]]; sB += hc * c.vb[c.n + c.hrow[k]]; }
-        const double base = prm.use_cvec ? c.cvec[j] : (prm.sigma * c.xy[j] - c.q[j]);
-        const bool gone = c.nelim && c.erow[j] >= 0;           // eliminated from the system: no residual, no direction
-        const double bj = gone ? 0.0 : base + sB;
-        const double rj = gone ? 0.0 : bj - prm.sigma * c.vx[j] - sA;
-        const double zj = c.minv[j] * rj;
-        c.init_r[(size_t)j * c.init_stride] = rj;
-        c.init_z[j] = zj;
-        if (c.u0pos) c.u0pos[c.u0map[j]] = zj;
-        prz += rj * zj; prr += rj * rj; pbb += bj * bj;
-      }
+    const int RL = lanes_for(b.r1 - b.r0), rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
+    for (int j = b.r0 + rg; j < b.r1; j += TB / RL) {
+      const int a0 = Mm.rowptr[j] - b.k0, a1 = Mm.rowptr[j + 1] - b.k0;
+      const double sA = row_sum_par(lprod, a0, a1, rlane, RL);
+      const double sB = row_sum_par(lprod + MAX_CHUNK, a0, a1, rlane, RL);
+      if (rlane == 0) row_start(j, sA, sB);
     }
     __syncthreads();
+  }
+  // long rows: one wavefront each, both products in one pass over the row (two whole-workgroup reductions per row made this
+  // kernel 44 us on the Lasso)
+  for (int bi = Mm.nstream + blockIdx.x * (TB / 64) + (threadIdx.x >> 6); bi < Mm.nblk; bi += gridDim.x * (TB / 64)) {
+    const RowBlk lb = Mm.blk[bi];
+    const int lane = threadIdx.x & 63;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    int k = lb.k0 + lane;
+    for (; k + 64 < lb.k1; k += 128) {
+      const int c0 = Mm.col16 ? (int)Mm.col16[k] : Mm.col[k], c1 = Mm.col16 ? (int)Mm.col16[k + 64] : Mm.col[k + 64];
+      const double v0 = Mm.val[k], v1 = Mm.val[k + 64];
+      a0 += v0 * c.vx[c0]; b0 += v0 * c.vb[c0]; a1 += v1 * c.vx[c1]; b1 += v1 * c.vb[c1];
+    }
+    if (k < lb.k1) { const int c0 = Mm.col16 ? (int)Mm.col16[k] : Mm.col[k]; const double v0 = Mm.val[k]; a0 += v0 * c.vx[c0]; b0 += v0 * c.vb[c0]; }
+    const double sA = wave_sum(a0 + a1), sB = wave_sum(b0 + b1);
+    if (lane == 0) row_start(lb.r0, sA, sB);
   }
   block_sum3(prz, prr, pbb, red);
   if (threadIdx.x == 0) {
@@ -927,44 +948,57 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
     if (ex) { c.vx[j] = xt + th * (xt - c.vold[j]); c.vold[j] = xt; }
     if (from_start) c.va[j] = xt;
   }
-  for (int bi = blockIdx.x; bi < c.A.nblk; bi += gridDim.x) {
+  // update_z / update_y of row i given z~_i = (A x~)_i (without the eliminated variable's term), by one thread
+  auto row_update = [&](int i, double zt) {
+    const double rho = c.rho[i], rinv = c.rhoinv[i], yo = y[i], zo = c.z[i];
+    const int ye = c.nelim ? c.ecol[i] : -1;
+    double rz = rho * zt, xny = 0.0;
+    if (ye >= 0) {
+      // zt so far is (A_X x~_X)_i: the PCG vector is zero at the eliminated variable.  Back substitution
+      // x~_y = (b_y - rho a (A_X x~_X)_i) / D_y with the b_y of the system just solved, then the variable's own update_x.
+      const double a = c.ecoef[i], xoy = x[ye];
+      const double by = (prm.use_cvec ? c.cvec[ye] : (prm.sigma * xoy - c.q[ye])) + a * (rho * zo - yo);
+      const double xty = (by - rho * a * zt) * c.edinv[i];
+      rz = c.rhoe[i] * zt;                     // what the operator of the reduced system applies to this row
+      zt += a * xty;
+      xny = alpha * xty + oma * xoy;
+      c.dxy[ye] = xny - xoy; x[ye] = xny; c.xte[i] = xty;
+    }
+    double v = alpha * zt + oma * zo + rinv * yo;
+    v = fmax(v, c.l[i]);
+    const double zn = fmin(v, c.u[i]);
+    const double dy = rho * (alpha * zt + oma * zo - zn);
+    const double yn = yo + dy;
+    c.z[i] = zn; y[i] = yn; c.dy[i] = dy; c.zt[i] = zt;
+    c.va[c.n + i] = rz;
+    if (ex) { c.vx[c.n + i] = rz + th * (rz - c.vold[c.n + i]); c.vold[c.n + i] = rz; }
+    c.vb[c.n + i] = ye >= 0 ? elim_vb(c, prm, i, rho, rho * zn - yn, xny) : rho * zn - yn;
+  };
+  // stream blocks (whole rows staged through LDS)
+  for (int bi = blockIdx.x; bi < c.A.nstream; bi += gridDim.x) {
     const RowBlk b = c.A.blk[bi];
-    const bool longrow = IS_LONG(b);
-    if (!longrow) {
-      stage_products<1>(c.A, b, xts, nullptr, lprod, nullptr);
-      __syncthreads();
+    stage_products<1>(c.A, b, xts, nullptr, lprod, nullptr);
+    __syncthreads();
+    const int RL = lanes_for(b.r1 - b.r0), rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
+    for (int i = b.r0 + rg; i < b.r1; i += TB / RL) {
+      const double zt = row_sum_par(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0, rlane, RL);
+      if (rlane == 0) row_update(i, zt);
     }
-    const int RL = longrow ? 1 : lanes_for(b.r1 - b.r0), rg = threadIdx.x / RL, rlane = threadIdx.x % RL;
-    for (int i = b.r0 + (longrow ? 0 : rg); i < b.r1; i += (longrow ? 1 : TB / RL)) {
-      double zt;
-      if (longrow) zt = bi >= c.A.nwave ? huge_row_sum(c, bi, red) : long_row_dot(c.A, b.k0, b.k1, xts, red);
-      else zt = row_sum_par(lprod, c.A.rowptr[i] - b.k0, c.A.rowptr[i + 1] - b.k0, rlane, RL);
-      if (longrow ? threadIdx.x == 0 : rlane == 0) {
-        const double rho = c.rho[i], rinv = c.rhoinv[i], yo = y[i], zo = c.z[i];
-        const int ye = c.nelim ? c.ecol[i] : -1;
-        double rz = rho * zt, xny = 0.0;
-        if (ye >= 0) {
-          // zt so far is (A_X x~_X)_i: the PCG vector is zero at the eliminated variable.  Back substitution
-          // x~_y = (b_y - rho a (A_X x~_X)_i) / D_y with the b_y of the system just solved, then the variable's own update_x.
-          const double a = c.ecoef[i], xoy = x[ye];
-          const double by = (prm.use_cvec ? c.cvec[ye] : (prm.sigma * xoy - c.q[ye])) + a * (rho * zo - yo);
-          const double xty = (by - rho * a * zt) * c.edinv[i];
-          rz = c.rhoe[i] * zt;                     // what the operator of the reduced system applies to this row
-          zt += a * xty;
-          xny = alpha * xty + oma * xoy;
-          c.dxy[ye] = xny - xoy; x[ye] = xny; c.xte[i] = xty;
-        }
-        double v = alpha * zt + oma * zo + rinv * yo;
-        v = fmax(v, c.l[i]);
-        const double zn = fmin(v, c.u[i]);
-        const double dy = rho * (alpha * zt + oma * zo - zn);
-        const double yn = yo + dy;
-        c.z[i] = zn; y[i] = yn; c.dy[i] = dy; c.zt[i] = zt;
-        c.va[c.n + i] = rz;
-        if (ex) { c.vx[c.n + i] = rz + th * (rz - c.vold[c.n + i]); c.vold[c.n + i] = rz; }
-        c.vb[c.n + i] = ye >= 0 ? elim_vb(c, prm, i, rho, rho * zn - yn, xny) : rho * zn - yn;
-      }
-    }
+    __syncthreads();
+  }
+  // long rows: the whole workgroup per row.  (One wavefront per row as in the PCG kernels is twice as fast on the Lasso's 10 000 rows
+  // -- 2 % of its ADMM iteration -- but z~ then differs in its last bits, and a solve at the floor of attainable accuracy
+  // (test_tight_tolerance_on_ill_conditioned_system, eps = 1e-9 on a cond 1e6 system) moved from 225 to 325 iterations: not worth it.)
+  for (int bi = c.A.nstream + blockIdx.x; bi < c.A.nwave; bi += gridDim.x) {
+    const RowBlk lb = c.A.blk[bi];
+    const double zt = long_row_dot(c.A, lb.k0, lb.k1, xts, red);
+    if (threadIdx.x == 0) row_update(lb.r0, zt);
+    __syncthreads();
+  }
+  // huge rows: partials left by k_huge_dot
+  for (int bi = c.A.nwave + blockIdx.x; bi < c.A.nblk; bi += gridDim.x) {
+    const double zt = huge_row_sum(c, bi, red);
+    if (threadIdx.x == 0) row_update(c.A.blk[bi].r0, zt);
     __syncthreads();
   }
 }
@@ -1146,8 +1180,9 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
 #ifdef OSQP_AMD_TIMELINE
   long long *tls = reinterpret_cast<long long *>(sval + 768);   // phase stamps of the first 64 exchanges (workgroup 0)
 #define RTL(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && nx >= 1 && nx <= 64) tls[(nx - 1) * 5 + (k)] = wall_clock64(); } while (0)
-  long long *wtl = tls + 5 * 64;                             // [phase][wavefront] stamps of exchange 8 (workgroup 0)
-#define WTL(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && nx == 8) wtl[(k) * 8 + (threadIdx.x >> 6)] = wall_clock64(); } while (0)
+  long long *wtl = tls + 5 * 64;                             // [phase][wavefront] stamps of exchange 8 (workgroup 0), then the same of exchange 1
+#define WTL(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (nx == 8 || nx == 1)) wtl[(nx == 1 ? 40 : 0) + (k) * 8 + (threadIdx.x >> 6)] = wall_clock64(); } while (0)
+  if (blockIdx.x == 0 && threadIdx.x == 0) wtl[80] = wall_clock64();       // kernel entry
 #else
 #define RTL(k) do { } while (0)
 #define WTL(k) do { } while (0)
@@ -1522,9 +1557,11 @@ __global__ void __launch_bounds__(RES_TB) k_pcg_resident(Ctx c, ResCtx rc) {
       c.tl[1 + k0 + cnt] = (15ull << 56) | (wall_clock64() & 0x00FFFFFFFFFFFFFFull);
     }
     if (nx >= 8) {
-      const unsigned long long k1 = atomicAdd(c.tl, 40ull);
-      if (k1 + 40 < TL_CAP - 2)
+      const unsigned long long k1 = atomicAdd(c.tl, 80ull);
+      if (k1 + 80 < TL_CAP - 2) {
         for (int q = 0; q < 40; ++q) c.tl[1 + k1 + q] = ((unsigned long long)(20 + q) << 56) | ((unsigned long long)(wtl[q] - wtl[0]) & 0x00FFFFFFFFFFFFFFull);
+        for (int q = 0; q < 40; ++q) c.tl[1 + k1 + 40 + q] = ((unsigned long long)(60 + q) << 56) | ((unsigned long long)(wtl[40 + q] - wtl[80]) & 0x00FFFFFFFFFFFFFFull);   // first trip, since kernel entry
+      }
     }
   }
 #endif
@@ -2267,6 +2304,7 @@ struct HostMat {         // host image of a device CSR matrix
   std::vector<double> val;
   std::vector<RowBlk> blk;
   int *d_rowptr = nullptr, *d_col = nullptr, *d_split = nullptr;
+  unsigned short *d_col16 = nullptr;
   double *d_val = nullptr;
   RowBlk *d_blk = nullptr;
 };
@@ -2403,6 +2441,13 @@ static int upload_mat(hipeng *e, HostMat &H) {
   }
   if (!H.blk.empty())
     HIPCHK(hipMemcpyAsync(H.d_blk, H.blk.data(), H.blk.size() * sizeof(RowBlk), hipMemcpyHostToDevice, e->stream));
+  if (H.nwave > H.nstream && !H.col.empty() && *std::max_element(H.col.begin(), H.col.end()) <= 0xffff) {
+    // long rows (one wavefront each in the PCG kernels) and every column id fits 16 bits: a second, narrower index array
+    std::vector<unsigned short> c16(H.col.begin(), H.col.end());
+    if (dev_alloc(e, &H.d_col16, c16.size())) return HIPENG_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(H.d_col16, c16.data(), c16.size() * sizeof(unsigned short), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));       // (the source is a local)
+  }
   if (!H.split.empty()) {
     if (dev_alloc(e, &H.d_split, H.split.size())) return HIPENG_ERR_HIP;
     HIPCHK(hipMemcpyAsync(H.d_split, H.split.data(), H.split.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
@@ -2413,7 +2458,7 @@ static int upload_mat(hipeng *e, HostMat &H) {
 static DevMat dev_view(const HostMat &H) {
   DevMat d;
   d.nrows = H.nrows; d.nblk = (int)H.blk.size(); d.nstream = H.nstream; d.nwave = H.nwave;
-  d.rowptr = H.d_rowptr; d.col = H.d_col; d.val = H.d_val; d.split = H.d_split; d.blk = H.d_blk;
+  d.rowptr = H.d_rowptr; d.col = H.d_col; d.col16 = H.d_col16; d.val = H.d_val; d.split = H.d_split; d.blk = H.d_blk;
   return d;
 }
 
@@ -2817,7 +2862,7 @@ static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr)
   }
   rc.wg = d_wg; rc.rowpos = d_rowpos; rc.col = d_col; rc.rowl = d_rowl; rc.krp = d_krp; rc.kcj = d_kcj; rc.kps = d_kps; rc.kdst = d_kdst; rc.brk = d_brk; rc.slot0 = d_slot0; rc.segrow = d_segrow;
   e->rc = rc;
-  e->res_lds = ((size_t)rc.npad + RES_TB + RES_MAXROWS + 3 + 16 + 768 + 5 * 64 + 48) * sizeof(double);   // + phase stamps of the TIMELINE build
+  e->res_lds = ((size_t)rc.npad + RES_TB + RES_MAXROWS + 3 + 16 + 768 + 5 * 64 + 96) * sizeof(double);   // + phase stamps of the TIMELINE build
   int rcode = 0;
   switch (E) {
     case 8: rcode = res_set_lds<8>(e->res_lds); break;   case 16: rcode = res_set_lds<16>(e->res_lds); break;

@@ -77,7 +77,9 @@ static void fill_params(hipeng_params *p, const osqp_amd_options *o, c_float sig
   /* solves outside an ADMM loop (LinSysSolver.solve, the convexity probe, polish) have no eps_abs/eps_rel to relate to:
    * 1e-10 unless the option asks for less; osqp_solve sets its own stop from the option and the tolerances */
   p->pcg_eps_rel = HMIN(o->pcg_eps_rel, 1e-10); p->pcg_eps_abs = o->pcg_eps_abs;
-  p->pcg_max_iter = o->pcg_max_iter > 0 ? o->pcg_max_iter : HMAX(1000, 2 * n);
+  /* the cap is for pathological systems only: in the 120-case random sweep (tools/stress.py) max(1000, 2n) cut 10 ill-conditioned small QPs short
+   * (pcg_forced), 20000 none, at the same run time */
+  p->pcg_max_iter = o->pcg_max_iter > 0 ? o->pcg_max_iter : HMAX(20000, 10 * n);
   p->no_restart = 0;
 }
 

@@ -261,7 +261,7 @@ class RowPartitionedOSQP:
 
     def _pcg(self, b, x0, eps_rel):
         n = self.n
-        cap = self.st["pcg_max_iter"] or max(1000, 2 * n)
+        cap = self.st["pcg_max_iter"] or max(20000, 10 * n)
         x = x0.clone()
         r = b - self._K(x)
         tol2 = max(eps_rel * eps_rel * float(b @ b), 1e-30)

@@ -40,6 +40,17 @@ if hasattr(L, "hipeng_timeline"):      # make TIMELINE=1 build: where the time o
                 v = v[v < 1e4]
                 row.append(v.mean() if v.size else float("nan"))
             print("   phase %d: " % ph + " ".join("%6.2f" % x for x in row))
+    w1 = (ids >= 60) & (ids < 100)
+    if w1.any():           # the FIRST trip of a launch (u0 read from memory): us since kernel entry, per wavefront
+        print("  first trip of a launch, workgroup 0, us since kernel entry (rows: u0 in LDS, products issued, scalars, barrier passed, update; columns: wavefronts 0..7)")
+        for ph in range(5):
+            row = []
+            for wv in range(8):
+                v = ts[ids == 60 + ph * 8 + wv]
+                v = v[v < 1e4]
+                row.append(v.mean() if v.size else float("nan"))
+            print("   phase %d: " % ph + " ".join("%6.2f" % x for x in row))
+    wsel = wsel | w1
     ids, ts = ids[~wsel], ts[~wsel]
     order = np.argsort(ts, kind="stable"); ids, ts = ids[order], ts[order]
     per = np.diff(ts)

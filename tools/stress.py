@@ -111,6 +111,7 @@ def main():
             print("case %d (%s, n=%d m=%d, %s): %s" % (case, kind, pb["q"].size, pb["l"].size, kw, "; ".join(msgs)), flush=True)
         if case % 20 == 19: print("... %d cases, %d flagged, %.0fs" % (case + 1, bad, time.time() - t0), flush=True)
     print("done: %d cases, %d flagged" % (n_cases, bad))
+    sys.exit(1 if bad else 0)        # (round 3: 0 flagged with the default PCG cap of max(20000, 10 n); max(1000, 2 n) left 10 cases with capped solves)
 
 
 if __name__ == "__main__":
