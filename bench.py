@@ -209,6 +209,11 @@ def other_configs(eps):
                 out[name]["resident_launch"] = dict(form={2: "k_pcg_blockres", 3: "k_blk_apply + k_blk_finish (block-direct)"}.get(int(info[9]), "k_pcg_resident"), usec=round(us_l, 1),
                                                     pcg_iterations=int(info[6]), usec_per_pcg_iteration=round(us_l / max(1, int(info[6])), 2),
                                                     bytes_read_once_per_launch_MB=round((s.nnzP * 2 - s.n) * 8 / 1e6, 1) if info[9] == 2 else None)
+                if info[9] == 3:
+                    # block-direct: one pass over the inverse blocks (same bytes as the dense blocks of P) per linear solve; the time
+                    # includes k_blk_finish (profiles/r03_config5_*: k_blk_apply alone 10.7 us = 4.85 TB/s)
+                    by = (s.nnzP * 2 - s.n) * 8.0
+                    out[name]["resident_launch"].update(algorithmic_MB=round(by / 1e6, 1), gbs=round(by / us_l / 1e3, 1), frac_of_8TBs=round(by / us_l / 1e3 / HBM_PEAK_GBS, 4))
         if name.startswith("config3"):
             # BASELINE config 3 / SURVEY 8(d): the gamma sweep through osqp_update_lin_cost with warm-started re-solves
             # (docs/examples/lasso.rst:41-63), then perturbed data through osqp_update_A (same pattern) and a warm-started

@@ -154,3 +154,38 @@ def test_plugin_solve_with_eliminated_variables(gpu_lib):
         xt = np.linalg.solve(K, rhs[:n] + A.T @ (rr * rhs[n:]))
         assert _rel(b[:n], xt) < 1e-8 and _rel(b[n:], A @ xt) < 1e-8
     s.contents.free(s)
+
+
+def test_random_qps_with_slack_variables(gpu_lib, oracle_mod):
+    """Random QPs in the form  min 1/2 x'Px + q'x + 1/2 s'Ws  s.t.  l <= Gx + c.s <= u  plus boxes on part of x: the slack
+    variables s (one row each; W_ii = 0 for some: only sigma holds them, some rows equalities, some one-sided) are eliminated;
+    settings vary (scaling on/off, rho, alpha).  Same iteration count, status and rho updates as the oracle, x and y to 1e-6."""
+    import osqp_amd
+    for case in range(8):
+        rng = np.random.default_rng(100 + case)
+        nx = int(rng.integers(40, 260)); ns = int(rng.integers(5, nx)); nb = int(rng.integers(0, nx // 2))
+        B = sparse.random(nx, nx, density=min(1.0, 3.0 / nx), random_state=case, data_rvs=rng.standard_normal, format="csc")
+        W = rng.uniform(0.0, 2.0, ns) * (rng.random(ns) < 0.7)          # 30 % of the slack variables have no cost at all
+        P = sparse.block_diag([B @ B.T + sparse.diags(rng.uniform(0.01, 1.0, nx)), sparse.diags(W)], format="csc")
+        G = sparse.random(ns, nx, density=min(1.0, 6.0 / nx), random_state=case + 50, data_rvs=rng.standard_normal, format="csc")
+        cs = rng.uniform(0.3, 3.0, ns) * rng.choice([-1.0, 1.0], ns)
+        rows = [sparse.hstack([G, sparse.diags(cs)])]
+        if nb: rows.append(sparse.hstack([sparse.eye(nx, format="csc")[:nb], sparse.csc_matrix((nb, ns))]))
+        A = sparse.vstack(rows, format="csc")
+        x0 = rng.standard_normal(nx + ns)
+        Ax = A @ x0
+        l = Ax - rng.uniform(0.0, 1.0, A.shape[0]); u = Ax + rng.uniform(0.0, 1.0, A.shape[0])
+        eq = rng.random(A.shape[0]) < 0.3; l[eq] = u[eq] = Ax[eq]
+        lo = rng.random(A.shape[0]) < 0.15; l[lo & ~eq] = -np.inf
+        pb = dict(P=P, q=rng.standard_normal(nx + ns), A=A, l=l, u=u)
+        kw = [dict(), dict(scaling=0), dict(rho=1.5, alpha=1.2), dict(eps_abs=1e-6, eps_rel=1e-6, adaptive_rho_interval=15)][case % 4]
+        with _env(OSQP_AMD_RESIDENT=0):
+            sg = osqp_amd.OSQP().setup(**pb, **kw)
+        so = oracle_mod.OracleOSQP().setup(**pb, **kw)
+        assert _elim_count(sg) >= ns, (case, _elim_count(sg), ns)      # (an x_j with no coupling in P and a single row of its own qualifies too)
+        rg, ro = sg.solve(), so.solve()
+        assert rg.info.status == ro.info.status, (case, rg.info.status, ro.info.status)
+        assert rg.info.iter == ro.info.iter and rg.info.rho_updates == ro.info.rho_updates, (case, rg.info.iter, ro.info.iter)
+        if ro.info.status == "solved":
+            assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6, (case, _rel(rg.x, ro.x), _rel(rg.y, ro.y))
+        assert sg.stats()["pcg_forced"] == 0
