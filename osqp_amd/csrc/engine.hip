@@ -1138,7 +1138,7 @@ __global__ void __launch_bounds__(TB) k_form_K(Ctx c, ResCtx rc) {
       for (int kc = ka; kc < kb; kc += 64) {
         const bool on = kc + lane < kb;
         const int kk = on ? c.M.col[kc + lane] - c.n : 0;
-        const double ai = on ? c.M.val[kc + lane] : 0.0, rk = on ? c.rho[kk] : 0.0;
+        const double ai = on ? c.M.val[kc + lane] : 0.0, rk = on ? c.rhoe[kk] : 0.0;     // (rhoe: the rows' effective weights when variables are eliminated, rho itself otherwise)
         const int p0 = on ? c.A.rowptr[kk] : 0, p1 = on ? c.A.rowptr[kk + 1] : 0;
         const int cnt = min(64, kb - kc);
         for (int q = 0; q < cnt; ++q) {
@@ -1158,10 +1158,16 @@ __global__ void __launch_bounds__(TB) k_form_K(Ctx c, ResCtx rc) {
           }
         }
       }
+      // eliminated variables (k_elim_refresh) are not part of the system the launch solves: their rows and columns of K hold
+      // nothing but a diagonal entry (the PCG vectors are zero there, so its value never enters a product)
+      const bool igone = c.nelim && c.erow[i] >= 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int idx = eb + q * 64 + lane;
-        if (idx < e1) rc.val[rc.kdst[idx]] = v[q];
+        if (idx < e1) {
+          const bool gone = c.nelim && (igone || c.erow[j[q]] >= 0);
+          rc.val[rc.kdst[idx]] = gone ? (j[q] == i ? 1.0 : 0.0) : v[q];
+        }
       }
     }
   }
@@ -1918,7 +1924,7 @@ __global__ void __launch_bounds__(TB) k_blk_finish(Ctx c, BdCtx bd) {
 }
 
 // ---------------------------------------------------------------------------
-// Elimination of slack-like variables from the linear system (launch-per-step kernels).
+// Elimination of slack-like variables from the linear system (launch-per-step kernels and the resident PCG).
 //
 // A variable y that (1) appears in exactly ONE row i of A (coefficient a), (2) has no off-diagonal entry in P and
 // (3) shares its row with no other such variable couples to the rest of K = P + sigma I + A' rho A only through that row:
@@ -1930,7 +1936,8 @@ __global__ void __launch_bounds__(TB) k_blk_finish(Ctx c, BdCtx bd) {
 // is huge against the Schur complement it hides and K is badly conditioned (Lasso, docs/examples/lasso.rst:41-63: the
 // residual variables y with y = Ad x - b; config 3 ran 98.6 PCG iterations per ADMM iteration); S has rho~ ~ P_yy + sigma
 // there.  Inertia: K > 0 <=> S > 0 and D > 0, so the convexity probe may run on the reduced operator too.
-// In the kernels: the PCG vectors are zero at the eliminated variables (k_pcg_init starts them so, k_cg_B keeps w_y = 0),
+// In the kernels: the PCG vectors are zero at the eliminated variables (k_pcg_init starts them so, k_cg_B keeps w_y = 0;
+// k_form_K gives their rows and columns of the resident K nothing but a diagonal entry and weighs the rows with rho~),
 // k_cg_A weighs rows with rho~ (Ctx::rhoe), k_admm_finalize back-substitutes and folds b_y into the m-part of the next
 // right-hand side.  The ADMM iterates themselves (x, z, y, residuals) never see any of this.
 // ---------------------------------------------------------------------------
@@ -3039,14 +3046,14 @@ static int push_params(hipeng *e) {
 }
 
 // Which variables can be eliminated from the linear system (see k_elim_refresh): exactly one entry in their column of A,
-// no off-diagonal entry in P, at most one such variable per row, the row not a huge one.  Launch-per-step engines only
-// (the resident forms hold K itself).  OSQP_AMD_ELIM=0 switches it off.
+// no off-diagonal entry in P, at most one such variable per row, the row not a huge one.  Launch-per-step engines and the
+// resident PCG (k_form_K forms the reduced operator then); not the block forms.  OSQP_AMD_ELIM=0 switches it off.
 static int build_elim(hipeng *e, const csc *P, const csc *A) {
   Ctx &c = e->c;
   c.nelim = 0; c.erow = c.ecol = c.epos = nullptr; c.rhoe = c.rho; c.ecoef = c.edinv = c.xte = nullptr;
   const int n = e->n, m = e->m;
   if (const char *x = getenv("OSQP_AMD_ELIM")) if (!atoi(x)) return 0;
-  if (e->res_on || m == 0 || n == 0) return 0;
+  if (e->res_kind >= 2 || m == 0 || n == 0) return 0;      // (the block forms of the portfolio family hold their own operator)
   std::vector<char> coupled(n, 0);
   for (int j = 0; j < n; j++)
     for (long long k = P->p[j]; k < P->p[j + 1]; k++) if (P->i[k] != j) { coupled[j] = 1; coupled[(int)P->i[k]] = 1; }

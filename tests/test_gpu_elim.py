@@ -43,18 +43,20 @@ def _lasso(nf, md, seed):
     return {k: pb[k] for k in "PqAlu"}, pb
 
 
-def test_lasso_with_eliminated_residual_variables(gpu_lib, oracle_mod):
+@pytest.mark.parametrize("resident", [0, 1])
+def test_lasso_with_eliminated_residual_variables(gpu_lib, oracle_mod, resident):
+    """resident = 0: launch-per-step kernels; 1: the resident PCG, whose k_form_K forms the reduced operator (n = 600 here)."""
     import osqp_amd
     data, pb = _lasso(150, 300, 3)
     nf, md = 150, 300
     kw = dict(eps_abs=1e-5, eps_rel=1e-5, adaptive_rho_interval=50)
-    with _env(OSQP_AMD_RESIDENT=0):
+    with _env(OSQP_AMD_RESIDENT=resident):
         sg = osqp_amd.OSQP().setup(**data, **kw)
         with _env(OSQP_AMD_ELIM=0):
             s0 = osqp_amd.OSQP().setup(**data, **kw)
     so = oracle_mod.OracleOSQP().setup(**data, **kw)
     assert _elim_count(sg) == md and _elim_count(s0) == 0          # y_1..y_md: one row each (y = Ad x - b), P_yy = 1
-    assert sg.stats()["resident"] == 0
+    assert sg.stats()["resident"] == resident == s0.stats()["resident"]
 
     def same(rg, ro, r0, txy=1e-6):
         assert rg.info.status == ro.info.status == r0.info.status == "solved"
