@@ -38,6 +38,7 @@
 #include <map>
 #include <algorithm>
 #include <mutex>
+#include <condition_variable>
 #include <chrono>
 #include "../../include/osqp_amd_engine.h"
 
@@ -2374,6 +2375,7 @@ struct hipeng {
   int res_fails = 0;         // launches that gave up waiting, in a row (one sends the rest of the run_admm call to the launch-per-step
                              // kernels; the third in a row sends the engine there for good; a call without one starts the count again)
   long long res_gave_up = 0; // ... since create
+  int res_cus = 248;         // CUs a process's resident launches may hold together on this device (all but one per XCD)
   long long res_slow = 0, res_slow_max = 0, res_repub = 0;   // State::res_slow / res_slow_max / res_repub added up over the windows
   long long res_slow_hist[4] = {0, 0, 0, 0}; unsigned res_slow_xcc = 0; int res_slow_last[4] = {0, 0, 0, 0};
   ResCtx rc{};
@@ -2631,7 +2633,25 @@ static int repack_dense(hipeng *e) {
 
 
 // ---- resident PCG: symbolic K, row partition, register layout --------------------------------------
-static std::mutex g_res_mu[16];
+// Resident launches need their workgroups co-resident, one per CU.  With grids sized to the problem several engines of one process
+// can be inside resident windows at the same time as long as their grids fit the device together: a per-device budget of CUs
+// (all but one per XCD), taken for the span launch ... sync of a window and handed back afterwards.  (Round 2 had a mutex here:
+// "one QP per stream" then meant one resident QP at a time.)  Across processes there is no such book-keeping: a launch that
+// finds CUs taken waits for them -- its first wait has 20 ms -- and gives up otherwise.
+struct CuBudget { std::mutex mu; std::condition_variable cv; int avail = -1; };
+static CuBudget g_res_cu[16];
+struct CuLease {
+  CuBudget *b = nullptr; int n = 0;
+  void take(int device, int total, int want) {
+    b = &g_res_cu[device & 15]; n = std::min(want, total);
+    std::unique_lock<std::mutex> lk(b->mu);
+    if (b->avail < 0) b->avail = total;
+    b->cv.wait(lk, [&] { return b->avail >= n; });
+    b->avail -= n;
+  }
+  void give() { if (b) { { std::lock_guard<std::mutex> lk(b->mu); b->avail += n; } b->cv.notify_all(); b = nullptr; } }
+  ~CuLease() { give(); }
+};
 static const int RES_E_LIST[] = {8, 16, 20, 24, 32, 48, 64};
 
 template <int E> static int res_set_lds(size_t lds) {
@@ -2695,6 +2715,7 @@ static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr)
     // restore an XCD's 32 x 570 KB of registers and LDS.  (Round 2's 1 ms wait limit turned each of them into a give-up.)
     nwg = std::min(256, prop.multiProcessorCount) - 8;
     if (const char *x = getenv("OSQP_AMD_RESIDENT_ALL_CUS")) if (atoi(x)) nwg += 8;
+    e->res_cus = nwg;
     if (prop.sharedMemPerBlock < 64 * 1024) RES_NO("too little LDS");
   }
   if (nwg <= 0 || nwg > 256 || (long long)nwg * RES_MAXROWS < n) RES_NO("too few CUs");
@@ -2999,6 +3020,7 @@ static int build_blockres(hipeng *e) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, e->device));
   const int nwg = std::min(256, prop.multiProcessorCount) - 8;       // one CU per XCD stays free (see build_resident)
+  e->res_cus = nwg;
   const int nb = (int)e->dP_blks.size();
   if (nb > 2 * nwg) RES_NO("more than two dense blocks per CU");
   // contiguous blocks, at most two and at most 256 rows per workgroup, spread evenly
@@ -3630,8 +3652,8 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     // A resident launch needs every CU for itself (one workgroup per CU, all co-resident): resident windows of
     // different engines of this process on one device take turns.  (Across processes there is no such lock: a
     // launch that finds CUs taken times out and the engine falls back, see k_pcg_resident.)
-    std::unique_lock<std::mutex> lease;
-    if (resident && e->res_kind != 3) lease = std::unique_lock<std::mutex>(g_res_mu[e->device & 15]);
+    CuLease lease;
+    if (resident && e->res_kind != 3) lease.take(e->device, e->res_cus, e->res_kind == 2 ? e->bc.nwg : e->rc.nwg);
     const long long burst = std::min<long long>(remaining, (e->calibrated || resident) ? 128 : 2);
     TR2(e, "launch burst=%lld K=%d", burst, e->K);
     // `burst` ADMM iterations = burst / segs graphs of `segs` segments + single-segment graphs for the rest
@@ -3645,7 +3667,7 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     for (; gR && left >= R; left -= R) { HIPCHK(hipGraphLaunch(gR, e->stream)); e->stats.graph_launches += 1; }
     for (; left > 0; left--) { HIPCHK(hipGraphLaunch(g1, e->stream)); e->stats.graph_launches += 1; }
     if (read_state(e, &s)) return HIPENG_ERR_HIP;
-    if (lease.owns_lock()) lease.unlock();
+    lease.give();
     e->res_slow += s.res_slow; e->res_slow_max = std::max<long long>(e->res_slow_max, s.res_slow_max); e->res_repub += s.res_repub;
     if (s.res_slow || s.res_repub) {
       for (int k = 0; k < 4; k++) { e->res_slow_hist[k] += s.res_slow_hist[k]; e->res_slow_last[k] = s.res_slow_last[k]; }
@@ -3855,8 +3877,8 @@ extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) 
   if (!e || !usec || reps <= 0 || which < 0 || which > 8) return HIPENG_ERR_ARG;
   if (which == 8 && !(e->res_on && e->res_fails < 3)) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
-  std::unique_lock<std::mutex> lease;
-  if (which == 8 && e->res_kind != 3) lease = std::unique_lock<std::mutex>(g_res_mu[e->device & 15]);
+  CuLease lease;
+  if (which == 8 && e->res_kind != 3) lease.take(e->device, e->res_cus, e->res_kind == 2 ? e->bc.nwg : e->rc.nwg);
   auto one = [&](int it) {
     // the first two kernels of a resident ADMM iteration: right-hand side + start residual, then the whole linear solve
     // (without k_admm_finalize the iterates do not move: every repetition solves the same system from the same start)
