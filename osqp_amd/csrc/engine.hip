@@ -39,6 +39,8 @@
 #include <algorithm>
 #include <mutex>
 #include <condition_variable>
+#include <thread>
+#include <atomic>
 #include <chrono>
 #include "../../include/osqp_amd_engine.h"
 
@@ -2688,6 +2690,18 @@ static void launch_resident(hipeng *e) {
   }
 }
 
+// Host-side set-up work of the resident PCG (symbolic K, register layout) is independent per row / per workgroup: a few threads.
+template <class F>
+static void parallel_chunks(int count, int min_chunk, F fn) {
+  int T = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char *x = getenv("OSQP_AMD_SETUP_THREADS")) T = std::max(1, std::min(64, atoi(x)));
+  T = std::min(T, std::max(1, count / min_chunk));
+  if (T <= 1) { fn(0, count, 0, 1); return; }
+  std::vector<std::thread> th;
+  for (int k = 0; k < T; k++) th.emplace_back([=, &fn] { fn((int)((long long)count * k / T), (int)((long long)count * (k + 1) / T), k, T); });
+  for (auto &t : th) t.join();
+}
+
 // Returns 0 (with e->res_on set when the problem qualifies) or a HIPENG error.  Not qualifying is not an error.
 #define RES_NO(why) do { if (e->trace) fprintf(stderr, "[osqp_amd] resident PCG not used: %s\n", why); return 0; } while (0)
 // What build_resident works out on the host before anything is uploaded (hipeng_resident_plan hands it to the CPU tests).
@@ -2725,27 +2739,49 @@ static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr)
     for (int k = M.split[i] + 1; k < M.rowptr[i + 1]; k++) if (M.col[k] <= M.col[k - 1]) RES_NO("a column of A is not sorted by row (or repeats one)");   // the merge in k_form_K wants ascending rows
   // pattern of K, row by row (sorted), with the slot of P(i,j) in M
   const size_t cap_total = (size_t)nwg * RES_PT * 64;
-  std::vector<int> Kptr(n + 1, 0), Kcol, Kps, mark(n, -1), pslot(n, -1);
-  Kcol.reserve(1 << 20); Kps.reserve(1 << 20);
-  for (int i = 0; i < n; i++) {
-    const size_t start = Kcol.size();
-    auto add = [&](int j) { if (mark[j] != i) { mark[j] = i; pslot[j] = -1; Kcol.push_back(j); } };
-    add(i);
-    for (int k = M.rowptr[i]; k < M.split[i]; k++) {
-      const int j = M.col[k];
-      add(j);
-      if (pslot[j] != -1) RES_NO("P repeats an entry");
-      pslot[j] = k;
+  std::vector<int> Kptr(n + 1, 0), Kcol, Kps;
+  {
+    // rows in contiguous chunks, one thread each with its own scratch; the chunks' lists are joined in order afterwards
+    std::vector<std::vector<int>> cKcol(64), cKps(64), cLen(64);
+    std::atomic<int> bad{0};
+    int used = 1;
+    parallel_chunks(n, 256, [&](int lo, int hi, int tid, int T) {
+      if (tid == 0) used = T;
+      std::vector<int> mark(n, -1), pslot(n, -1);
+      std::vector<int> &kc = cKcol[tid], &kp = cKps[tid], &ln = cLen[tid];
+      kc.reserve((size_t)(hi - lo) * 64); ln.reserve(hi - lo);
+      for (int i = lo; i < hi && !bad.load(std::memory_order_relaxed); i++) {
+        const size_t start = kc.size();
+        auto add = [&](int j) { if (mark[j] != i) { mark[j] = i; pslot[j] = -1; kc.push_back(j); } };
+        add(i);
+        for (int k = M.rowptr[i]; k < M.split[i]; k++) {
+          const int j = M.col[k];
+          add(j);
+          if (pslot[j] != -1) { bad = 1; break; }
+          pslot[j] = k;
+        }
+        for (int k = M.split[i]; k < M.rowptr[i + 1]; k++) {
+          const int row = M.col[k] - n;
+          for (int q = A.rowptr[row]; q < A.rowptr[row + 1]; q++) add(A.col[q]);
+        }
+        if (kc.size() > cap_total) { bad = 2; break; }
+        std::sort(kc.begin() + start, kc.end());
+        kp.resize(kc.size());
+        for (size_t q = start; q < kc.size(); q++) kp[q] = pslot[kc[q]];
+        ln.push_back((int)(kc.size() - start));
+      }
+    });
+    if (bad.load() == 1) RES_NO("P repeats an entry");
+    size_t tot = 0;
+    for (int k = 0; k < used; k++) tot += cKcol[k].size();
+    if (bad.load() == 2 || tot > cap_total) RES_NO("K has more entries than the register files hold");
+    Kcol.reserve(tot); Kps.reserve(tot);
+    int row = 0;
+    for (int k = 0; k < used; k++) {
+      Kcol.insert(Kcol.end(), cKcol[k].begin(), cKcol[k].end());
+      Kps.insert(Kps.end(), cKps[k].begin(), cKps[k].end());
+      for (int len : cLen[k]) { Kptr[row + 1] = Kptr[row] + len; row++; }
     }
-    for (int k = M.split[i]; k < M.rowptr[i + 1]; k++) {
-      const int row = M.col[k] - n;
-      for (int q = A.rowptr[row]; q < A.rowptr[row + 1]; q++) add(A.col[q]);
-    }
-    if (Kcol.size() > cap_total) RES_NO("K has more entries than the register files hold");
-    std::sort(Kcol.begin() + start, Kcol.end());
-    Kps.resize(Kcol.size());
-    for (size_t q = start; q < Kcol.size(); q++) Kps[q] = pslot[Kcol[q]];
-    Kptr[i + 1] = (int)Kcol.size();
   }
   const long long nnzK = Kptr[n];
   const auto tb1 = std::chrono::steady_clock::now();
@@ -2821,7 +2857,9 @@ static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr)
   std::vector<unsigned char> rowl(slots, 0);
   std::vector<int> kdst((size_t)nnzK, 0);
   std::vector<unsigned long long> brk((size_t)nwg * RES_PT, 0ull);
-  for (int g = 0; g < nwg; g++) {
+  std::atomic<int> seg_over{0};
+  parallel_chunks(nwg, 4, [&](int g_lo, int g_hi, int, int) {        // workgroups write disjoint parts of every array
+  for (int g = g_lo; g < g_hi; g++) {
     const ResWG &w = wg[g];
     if (w.nr == 0) continue;
     const int base = Kptr[w.r0];
@@ -2871,8 +2909,10 @@ static int build_resident(hipeng *e, int plan_nwg = 0, ResPlanOut *po = nullptr)
       brk[(size_t)g * RES_PT + t] = b;
     }
     for (int r = next_row; r <= RES_MAXROWS; r++) segrow[(size_t)g * (RES_MAXROWS + 1) + r] = (unsigned short)nseg;
-    if (nseg > RES_TB + RES_MAXROWS) return 0;   // cannot happen (one segment per thread plus one per row change)
+    if (nseg > RES_TB + RES_MAXROWS) seg_over = 1;   // cannot happen (one segment per thread plus one per row change)
   }
+  });
+  if (seg_over.load()) return 0;
   const auto tb2 = std::chrono::steady_clock::now();
   if (po) {                      // plan only (no device): hand the layout out
     po->ok = true; po->nwg = nwg; po->E = E; po->npad = npad; po->nnzK = nnzK;

@@ -134,3 +134,19 @@ def test_the_grid_is_sized_to_the_problem():
     P, A = _qp(300, 200, 300, 0.02)
     st256, _ = _plan(P, A, 256)
     assert st256[3] == _plan(P, A, -256)[0][3] and st256[2] > _plan(P, A, -256)[0][2]
+
+
+def test_the_plan_does_not_depend_on_the_number_of_setup_threads(monkeypatch):
+    """build_resident splits the symbolic K by rows and the register layout by workgroups over host threads
+    (OSQP_AMD_SETUP_THREADS): every array of the plan is the same for 1, 3 and 8 of them."""
+    P, A = _qp(3000, 2000, 11, 0.003)
+    plans = []
+    for k in ("1", "3", "8"):
+        monkeypatch.setenv("OSQP_AMD_SETUP_THREADS", k)
+        st, pl = _plan(P, A, -256)
+        assert st[0] == 1
+        plans.append((st, pl))
+    for st, pl in plans[1:]:
+        assert st == plans[0][0]
+        for key in pl:
+            assert np.array_equal(pl[key], plans[0][1][key]), key
