@@ -159,7 +159,7 @@ c_int hipeng_elim_count(hipeng *e);
  * gave up waiting since create (each sends the rest of its run_admm call to the launch-per-step kernels), [11] waits inside
  * resident launches that ended well but took more than 50 us, [12] the longest of them in ticks of the 100 MHz clock,
  * [13] flags / granules stored again by a workgroup whose own wait went on, [14] give-ups in a row (the third ends the mode
- * for this engine; a run_admm call without one starts the count again), [15] reserved.  [1] stays 1 until that third one. */
+ * for this engine; a run_admm call without one starts the count again), [15] block-direct form: coupling rows of A carried as the low-rank term (0: the plain form, huge rows only).  [1] stays 1 until that third one. */
 int hipeng_resident_info(hipeng *e, long long out[16]);
 /* For the CPU tests (needs no device): the host side of the resident set-up -- symbolic K, row partition, positions in
  * the exchanged vector, register layout -- for a grid of exactly `nwg` workgroups (nwg > 0) or, nwg < 0, with the grid sized

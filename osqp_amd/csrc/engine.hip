@@ -388,7 +388,8 @@ __device__ __forceinline__ double wave_row_dot(const DevMat &Mx, int ka, int kb,
 // (<= 32 rows per wavefront); the four partial vectors meet in LDS.  No index loads, no gathers.
 // Returns y_r for r = threadIdx.x < b (0 otherwise); scratch: 5*DENSE_MAX doubles, x_b is left
 // in scratch[4*DENSE_MAX ...].  Ends with a barrier; the caller adds one before reusing scratch.
-__device__ __forceinline__ double dense_block_mv(const DenseP &dP, const DenseBlk d, const double *x, double *scratch) {
+template <class XL>
+__device__ __forceinline__ double dense_block_mv_x(const DenseP &dP, const DenseBlk d, XL xload, double *scratch) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const double2 *dv = reinterpret_cast<const double2 *>(dP.val + d.off);
   const int hp = d.pitch >> 1;
@@ -399,7 +400,7 @@ __device__ __forceinline__ double dense_block_mv(const DenseP &dP, const DenseBl
     v[q] = (j < d.b && lane < hp) ? dv[(size_t)j * hp + lane] : double2{0.0, 0.0};
   }
   double *xl = scratch + 4 * DENSE_MAX;
-  if ((int)threadIdx.x < DENSE_MAX) xl[threadIdx.x] = (int)threadIdx.x < d.b ? x[d.c0 + threadIdx.x] : 0.0;
+  if ((int)threadIdx.x < DENSE_MAX) xl[threadIdx.x] = (int)threadIdx.x < d.b ? xload(d.c0 + (int)threadIdx.x) : 0.0;
   __syncthreads();
   double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -411,6 +412,9 @@ __device__ __forceinline__ double dense_block_mv(const DenseP &dP, const DenseBl
   __syncthreads();
   const int r = threadIdx.x;
   return r < d.b ? (scratch[r] + scratch[DENSE_MAX + r]) + (scratch[2 * DENSE_MAX + r] + scratch[3 * DENSE_MAX + r]) : 0.0;
+}
+__device__ __forceinline__ double dense_block_mv(const DenseP &dP, const DenseBlk d, const double *x, double *scratch) {
+  return dense_block_mv_x(dP, d, [x](int j) { return x[j]; }, scratch);
 }
 
 #define LDS_DECL(NV)                                   \
@@ -1848,6 +1852,14 @@ struct BdCtx {
   double *cinv;            // [nh][nh] (R_h^-1 + A_h W)^-1
   double *part;            // [MAX_HUGE_FOLD][nblk] partials of A_h t per block
   int    *flag;            // [0] a pivot was not positive
+  // coupled form (kc > 0): EVERY row of A with two or more entries -- sector rows, the budget row, whatever their length -- is a
+  // term of the low-rank part; nothing of W is stored (see k_cpl_dot)
+  int     kc;
+  const int *crow;         // [kc] the coupling rows of A
+  const int *cidx;         // [m] position of a row in crow, -1 for the single-entry rows
+  double *cs, *cc;         // [kc] S t and Cinv S t
+  double *cap;             // [kc][kc] capacitance matrix R^-1 + S B^-1 S', inverted in place (k_cap_invert)
+  double *t2;              // [n] scratch of the refresh
 };
 
 __global__ void __launch_bounds__(TB) k_blk_invert(Ctx c, BdCtx bd) {
@@ -1866,7 +1878,11 @@ __global__ void __launch_bounds__(TB) k_blk_invert(Ctx c, BdCtx bd) {
     if (t < b) {                       // diagonal: sigma + the single-entry rows of A at this column (the huge rows are the low-rank part)
       const int jj = d.c0 + t;
       double dadd = sigma;
-      for (int k = c.Mk.rowptr[jj]; k < c.Mk.rowptr[jj + 1]; ++k) { const double a = c.Mk.val[k]; dadd += c.rho[c.Mk.col[k] - c.n] * a * a; }
+      for (int k = c.Mk.rowptr[jj]; k < c.Mk.rowptr[jj + 1]; ++k) {
+        const int row = c.Mk.col[k] - c.n;
+        if (bd.kc && bd.cidx[row] >= 0) continue;           // (coupled form: such a row is part of S)
+        const double a = c.Mk.val[k]; dadd += c.rho[row] * a * a;
+      }
       bl[t * b + t] += dadd;
     }
     __syncthreads();
@@ -1905,7 +1921,7 @@ __global__ void __launch_bounds__(TB) k_blk_apply(Ctx c, BdCtx bd, const double 
     const int j = d.c0 + threadIdx.x;
     const bool on = (int)threadIdx.x < d.b;
     if (on) out[j] = y;
-    for (int h = 0; h < c.nh; ++h) {
+    if (!bd.kc) for (int h = 0; h < c.nh; ++h) {
       const double s = block_sum(on ? c.hcol[(size_t)h * c.n + j] * y : 0.0, red);
       if (threadIdx.x == 0) bd.part[(size_t)h * c.dP.nblk + db] = s;
     }
@@ -1940,6 +1956,94 @@ __global__ void __launch_bounds__(TB) k_blk_finish(Ctx c, BdCtx bd) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->iters[0] = 1; st->iters[1] = 0; st->done = 1;
     if (*bd.flag) st->neg_curv = 1;
+  }
+}
+
+// ---- coupled form: P = dense diagonal blocks, A = single-entry rows + kc <= CPL_MAX rows of any shape ---------------------------
+// (SURVEY C5 "+ 500 sparse sector rows": rows that tie variables of different blocks together.)  K = B + S' R S with S the kc
+// coupling rows, and   K^-1 r = t - B^-1 S' c,   t = B^-1 r,   c = (R^-1 + S B^-1 S')^-1 S t.   W = B^-1 S' would be n x kc dense
+// (200 MB at 500 rows), so it is never formed: the second term is a second pass over the inverse blocks (50 MB).  Per solve:
+//     k_blk_apply (t)  ->  k_cpl_dot (S t, one workgroup per coupling row)  ->  k_cpl_solve (c: kc x kc dense product, one wavefront
+//     per row)  ->  k_blk_apply_back (S' c gathered on the fly as the input of the block product; x~ = x~0 + t - result).
+// The capacitance matrix is built at refresh from kc block passes (column r = S B^-1 S' e_r) and inverted by one workgroup
+// in place (k_cap_invert: Gauss-Jordan without pivoting, the matrix is positive definite when K is).
+#define CPL_MAX 512
+__global__ void __launch_bounds__(TB) k_cpl_dot(Ctx c, BdCtx bd, const double *x, double *out, int gated) {
+  if (gated) { const State *st = c.st; if (st->stalled || !st->run) return; }
+  __shared__ double red[16];
+  const int i = bd.crow[blockIdx.x];
+  double s = 0.0;
+  for (int k = c.A.rowptr[i] + (int)threadIdx.x; k < c.A.rowptr[i + 1]; k += TB) s += c.A.val[k] * x[c.A.col[k]];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(TB) k_cpl_solve(Ctx c, BdCtx bd) {
+  { const State *st = c.st; if (st->stalled || !st->run) return; }
+  const int r = blockIdx.x * (TB / 64) + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= bd.kc) return;
+  double s = 0.0;
+  for (int q = lane; q < bd.kc; q += 64) s += bd.cap[(size_t)r * bd.kc + q] * bd.cs[q];
+  s = wave_sum(s);
+  if (lane == 0) bd.cc[r] = s;
+}
+// entry j of S' v for a kc-vector v (unit >= 0: of S' e_unit): the A' part of row j of M, coupling rows only
+__device__ __forceinline__ double cpl_back_entry(const Ctx &c, const BdCtx &bd, const double *v, int unit, int j) {
+  double s = 0.0;
+  for (int k = c.M.split[j]; k < c.M.rowptr[j + 1]; ++k) {
+    const int q = bd.cidx[c.M.col[k] - c.n];
+    if (q < 0) continue;
+    if (unit >= 0) { if (q == unit) s += c.M.val[k]; }
+    else s += c.M.val[k] * v[q];
+  }
+  return s;
+}
+// fin: x~ = x~0 + t - B^-1 S' c, the solve is complete.  Otherwise (refresh): out = B^-1 S' e_unit.
+__global__ void __launch_bounds__(TB) k_blk_apply_back(Ctx c, BdCtx bd, int unit, double *out, int fin) {
+  State *st = c.st;
+  if (fin && (st->stalled || !st->run)) return;
+  __shared__ double scratch[5 * DENSE_MAX];
+  const DenseP inv{c.dP.nblk, c.dP.blk, bd.binv};
+  for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
+    const DenseBlk d = c.dP.blk[db];
+    const double y = dense_block_mv_x(inv, d, [&](int j) { return cpl_back_entry(c, bd, bd.cc, unit, j); }, scratch);
+    const int j = d.c0 + threadIdx.x;
+    if ((int)threadIdx.x < d.b) { if (fin) c.va[j] = c.vx[j] + (bd.t[j] - y); else out[j] = y; }
+    __syncthreads();
+  }
+  if (fin && blockIdx.x == 0 && threadIdx.x == 0) {
+    st->iters[0] = 1; st->iters[1] = 0; st->done = 1;
+    if (*bd.flag) st->neg_curv = 1;
+  }
+}
+// cap <- (cap + R^-1)^-1 in place, one workgroup: thread <-> column j and the rows i0, i0 + 2, ... as k_blk_invert, the matrix in
+// global memory (2 MB at 512 rows: L2), the pivot row and column of each step in LDS
+__global__ void __launch_bounds__(2 * CPL_MAX) k_cap_invert(Ctx c, BdCtx bd) {
+  __shared__ double colp[CPL_MAX], rowp[CPL_MAX];
+  const int kc = bd.kc, t = threadIdx.x, j = t & (CPL_MAX - 1), i0 = t / CPL_MAX;
+  double *C = bd.cap;
+  if (t < kc) {
+    const double rho = c.rho[bd.crow[t]];
+    if (!(rho > 0.0)) atomicOr(bd.flag, 1);
+    C[(size_t)t * kc + t] += 1.0 / rho;
+  }
+  __syncthreads();
+  for (int p = 0; p < kc; ++p) {
+    if (t < kc) { colp[t] = C[(size_t)t * kc + p]; rowp[t] = C[(size_t)p * kc + t]; }
+    __syncthreads();
+    const double piv = rowp[p];
+    if (!(piv > 0.0) && t == 0) atomicOr(bd.flag, 1);
+    const double inv = 1.0 / piv;
+    if (j < kc) {
+      const double rj = rowp[j] * inv;
+      for (int i = i0; i < kc; i += 2) {
+        double v;
+        if (i == p) v = (j == p) ? inv : rj;
+        else if (j == p) v = -colp[i] * inv;
+        else v = C[(size_t)i * kc + j] - colp[i] * rj;
+        C[(size_t)i * kc + j] = v;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -2664,6 +2768,12 @@ static void launch_resident(hipeng *e) {
   if (e->res_kind == 3) {
     const int gb = std::max(1, std::min(1024, e->c.dP.nblk));
     hipLaunchKernelGGL(k_blk_apply, dim3(gb), dim3(TB), 0, e->stream, e->c, e->bd, (const double *)e->c.init_r, e->bd.t, 1);
+    if (e->bd.kc) {
+      hipLaunchKernelGGL(k_cpl_dot, dim3(e->bd.kc), dim3(TB), 0, e->stream, e->c, e->bd, (const double *)e->bd.t, e->bd.cs, 1);
+      hipLaunchKernelGGL(k_cpl_solve, dim3((e->bd.kc + TB / 64 - 1) / (TB / 64)), dim3(TB), 0, e->stream, e->c, e->bd);
+      hipLaunchKernelGGL(k_blk_apply_back, dim3(gb), dim3(TB), 0, e->stream, e->c, e->bd, -1, (double *)nullptr, 1);
+      return;
+    }
     hipLaunchKernelGGL(k_blk_finish, dim3(std::max(1, std::min(256, (e->n + TB - 1) / TB))), dim3(TB), 0, e->stream, e->c, e->bd);
     return;
   }
@@ -2981,13 +3091,41 @@ static bool blocks_eligible(hipeng *e) {
   for (int i = 0; i < e->m; i++) if (!ishuge[i] && e->A.rowptr[i + 1] - e->A.rowptr[i] != 1) return false;
   return true;
 }
+// Coupled form of the block-direct solve: the blocks tile 0..n and at most CPL_MAX rows of A have two or more entries (any
+// length, any pattern).  `rows` receives them.
+static bool blocks_coupled_eligible(hipeng *e, std::vector<int> &rows) {
+  if (e->dP_blks.empty()) return false;
+  int next = 0;
+  for (const DenseBlk &d : e->dP_blks) { if (d.c0 != next || d.b > DENSE_MAX) return false; next += d.b; }
+  if (next != e->n) return false;
+  int cap = CPL_MAX;
+  if (const char *x = getenv("OSQP_AMD_BLOCK_COUPLED_MAX")) cap = std::max(0, std::min(CPL_MAX, atoi(x)));
+  rows.clear();
+  for (int i = 0; i < e->m; i++) if (e->A.rowptr[i + 1] - e->A.rowptr[i] >= 2) { if ((int)rows.size() >= cap) return false; rows.push_back(i); }
+  return !rows.empty();
+}
 static int build_blockdirect(hipeng *e) {
   int want = 1;
   if (const char *x = getenv("OSQP_AMD_RESIDENT")) want = atoi(x);
   if (const char *x = getenv("OSQP_AMD_RESIDENT_BLOCKS")) want = want && atoi(x);
   if (const char *x = getenv("OSQP_AMD_BLOCK_DIRECT")) want = want && atoi(x);
-  if (!want || !blocks_eligible(e)) return 0;
+  if (!want) return 0;
+  std::vector<int> crows;
+  const bool plain = blocks_eligible(e);
+  if (!plain && !blocks_coupled_eligible(e, crows)) return 0;
   BdCtx bd{};
+  if (!plain) {
+    int *d_crow = nullptr, *d_cidx = nullptr;
+    const size_t kc = crows.size();
+    std::vector<int> cidx((size_t)std::max(1, e->m), -1);
+    for (size_t r = 0; r < kc; r++) cidx[crows[r]] = (int)r;
+    if (dev_alloc(e, &d_crow, kc) || dev_alloc(e, &d_cidx, cidx.size()) || dev_alloc(e, &bd.cs, kc) || dev_alloc(e, &bd.cc, kc) ||
+        dev_alloc(e, &bd.cap, kc * kc) || dev_alloc(e, &bd.t2, (size_t)e->n)) return HIPENG_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(d_crow, crows.data(), kc * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d_cidx, cidx.data(), cidx.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));          // (the sources are locals)
+    bd.kc = (int)kc; bd.crow = d_crow; bd.cidx = d_cidx;
+  }
   const size_t nd = e->dP_src.size(), n = (size_t)e->n, nb = e->dP_blks.size();
   if (dev_alloc(e, &bd.binv, nd) || dev_alloc(e, &bd.t, n) || dev_alloc(e, &bd.wh, (size_t)MAX_HUGE_FOLD * n) ||
       dev_alloc(e, &bd.cinv, (size_t)MAX_HUGE_FOLD * MAX_HUGE_FOLD) || dev_alloc(e, &bd.part, (size_t)MAX_HUGE_FOLD * nb) || dev_alloc(e, &bd.flag, 4)) return HIPENG_ERR_HIP;
@@ -2999,7 +3137,8 @@ static int build_blockdirect(hipeng *e) {
   // the solve kernels read the residual as a plain n-vector
   e->c.init_r = e->c.r; e->c.init_stride = 1;
   e->res_kind = 3; e->res_on = e->res_use = true;
-  if (e->trace) fprintf(stderr, "[osqp_amd] block-direct solve: %zu dense blocks inverted explicitly, %d huge rows of A as a Woodbury term\n", nb, (int)e->hrows.size());
+  if (e->trace) fprintf(stderr, "[osqp_amd] block-direct solve: %zu dense blocks inverted explicitly, %d %s of A as a Woodbury term\n", nb,
+                        bd.kc ? bd.kc : (int)e->hrows.size(), bd.kc ? "coupling rows" : "huge rows");
   return 0;
 }
 // New rho, sigma or matrix values: invert the blocks again, W = B^-1 A_h', capacitance matrix R_h^-1 + A_h W and its inverse.
@@ -3010,6 +3149,18 @@ static int blk_refresh(hipeng *e) {
   int bmax = 1;
   for (const DenseBlk &d : e->dP_blks) bmax = std::max(bmax, d.b);
   hipLaunchKernelGGL(k_blk_invert, dim3(std::min(nb, 1024)), dim3(TB), (size_t)bmax * bmax * sizeof(double), e->stream, e->c, e->bd);
+  if (e->bd.kc) {
+    // capacitance matrix, row r = S (B^-1 S' e_r): a block pass and kc row dots per coupling row, all on the stream
+    const int kc = e->bd.kc;
+    for (int r = 0; r < kc; r++) {
+      hipLaunchKernelGGL(k_blk_apply_back, dim3(std::min(nb, 1024)), dim3(TB), 0, e->stream, e->c, e->bd, r, e->bd.t2, 0);
+      hipLaunchKernelGGL(k_cpl_dot, dim3(kc), dim3(TB), 0, e->stream, e->c, e->bd, (const double *)e->bd.t2, e->bd.cap + (size_t)r * kc, 0);
+    }
+    hipLaunchKernelGGL(k_cap_invert, dim3(1), dim3(2 * CPL_MAX), 0, e->stream, e->c, e->bd);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+  }
   std::vector<double> C((size_t)MAX_HUGE_FOLD * MAX_HUGE_FOLD, 0.0), part((size_t)MAX_HUGE_FOLD * nb);
   for (int h = 0; h < nh; h++) {
     hipLaunchKernelGGL(k_blk_apply, dim3(std::min(nb, 1024)), dim3(TB), 0, e->stream, e->c, e->bd, (const double *)(c.hcol + (size_t)h * n), e->bd.wh + (size_t)h * n, 0);
@@ -4021,7 +4172,7 @@ extern "C" int hipeng_resident_info(hipeng *e, long long out[16]) {
   if (read_state(e, &s)) return HIPENG_ERR_HIP;
   out[0] = e->res_on; out[1] = e->res_on && e->res_fails < 3; out[2] = e->rc.E; out[3] = e->rc.nwg; out[4] = e->res_nnz; out[5] = (long long)e->res_lds;
   out[6] = std::max(s.iters[0], s.iters[1]); out[7] = s.res_pipe_off; out[8] = s.res_chk_fail; out[9] = e->res_kind; out[10] = e->res_gave_up; out[11] = e->res_slow + s.res_slow;
-  out[12] = std::max<long long>(e->res_slow_max, s.res_slow_max); out[13] = e->res_repub + s.res_repub; out[14] = e->res_fails; out[15] = 0;
+  out[12] = std::max<long long>(e->res_slow_max, s.res_slow_max); out[13] = e->res_repub + s.res_repub; out[14] = e->res_fails; out[15] = e->res_kind == 3 ? e->bd.kc : 0;
   if (e->res_kind == 2) { out[2] = 64; out[3] = e->bc.nwg; out[4] = 0; out[5] = 0; }
   if (e->res_kind == 3) { out[2] = 0; out[3] = e->c.dP.nblk; out[4] = 0; out[5] = 0; }
   return 0;

@@ -42,7 +42,7 @@ def _info(solver):
     out = (C.c_longlong * 16)()
     assert L.hipeng_resident_info(solver.engine(), out) == 0
     return dict(built=out[0], in_use=out[1], E=out[2], nwg=out[3], nnzK=out[4], lds=out[5], last_iters=out[6], pipe_off=out[7], checks_failed=out[8], form=out[9], gave_up=out[10],
-                slow_waits=out[11], slow_max_ticks=out[12], republished=out[13], strikes=out[14])
+                slow_waits=out[11], slow_max_ticks=out[12], republished=out[13], strikes=out[14], coupling_rows=out[15])
 
 
 def _qp(n, m, seed, eq=0, dens=0.02):
@@ -206,6 +206,47 @@ def test_block_forms_of_the_portfolio_match_oracle(gpu_lib, oracle_mod, direct):
     r2 = s2.solve()
     assert r2.info.iter == rg.info.iter and _rel(r2.x, rg.x) < 1e-7 and _rel(r2.y, rg.y) < 1e-7
     assert _info(sg)["gave_up"] == 0
+
+
+@pytest.mark.parametrize("nb,b,rows", [(8, 40, 5), (72, 125, 40), (24, 100, 300)])
+def test_block_direct_with_sector_rows_matches_oracle(gpu_lib, oracle_mod, nb, b, rows):
+    """SURVEY C5 "+ sparse sector rows": rows of A that tie variables of different blocks together.  The block-direct solve
+    carries EVERY multi-entry row of A (the sector rows and the budget row) as the low-rank term of a Woodbury solve whose
+    capacitance matrix is formed and inverted on the device (k_cpl_dot / k_cpl_solve / k_blk_apply_back / k_cap_invert).  Same
+    trajectory as the oracle's direct solve, also after new bounds, an osqp_update_rho and new values of A; and one application of
+    K^-1 per ADMM iteration."""
+    import osqp_amd
+    from osqp_amd.problems import portfolio_qp
+    pb = portfolio_qp(nb, b, sector_rows=rows, seed=7)
+    kw = dict(eps_abs=1e-4, eps_rel=1e-4)
+    sg = osqp_amd.OSQP().setup(**pb, **kw)
+    so = oracle_mod.OracleOSQP().setup(**pb, **kw)
+    inf = _info(sg)
+    multi = int((np.diff(pb["A"].tocsr().indptr) >= 2).sum())
+    assert multi >= 2 and inf["built"] and inf["form"] == 3 and inf["coupling_rows"] == multi, inf
+    rg, ro = sg.solve(), so.solve()
+    assert rg.info.status == ro.info.status == "solved"
+    assert rg.info.iter == ro.info.iter and rg.info.rho_updates == ro.info.rho_updates
+    assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
+    assert abs(rg.info.obj_val - ro.info.obj_val) <= 1e-6 * max(1.0, abs(ro.info.obj_val))
+    st = sg.stats()
+    assert st["pcg_iters_total"] == rg.info.iter and st["pcg_forced"] == 0
+    u2 = pb["u"].copy(); u2[-rows:] *= 0.8                       # tighter sector caps
+    sg.update(u=u2); so.update(u=u2)
+    rg2, ro2 = sg.solve(), so.solve()
+    assert rg2.info.iter == ro2.info.iter and _rel(rg2.x, ro2.x) < 1e-6 and _rel(rg2.y, ro2.y) < 1e-6
+    sg.update_rho(0.4); so.update_rho(0.4)                      # blocks and capacitance matrix are formed again
+    rg3, ro3 = sg.solve(), so.solve()
+    assert rg3.info.iter == ro3.info.iter and _rel(rg3.x, ro3.x) < 1e-6 and _rel(rg3.y, ro3.y) < 1e-6
+    Ax = pb["A"].data.copy(); Ax[pb["A"].indices > pb["A"].shape[0] - rows - 1] *= 1.1     # new values in the sector rows
+    sg.update(Ax=Ax); so.update(Ax=Ax)
+    rg4, ro4 = sg.solve(), so.solve()
+    assert rg4.info.iter == ro4.info.iter and _rel(rg4.x, ro4.x) < 1e-6 and _rel(rg4.y, ro4.y) < 1e-6
+    with _env(OSQP_AMD_BLOCK_COUPLED_MAX=0):                    # the same problem on the launch-per-step kernels
+        s2 = osqp_amd.OSQP().setup(**pb, **kw)
+    assert _info(s2)["form"] != 3
+    r2 = s2.solve()
+    assert r2.info.iter == rg.info.iter and _rel(r2.x, rg.x) < 1e-6 and _rel(r2.y, rg.y) < 1e-6
 
 
 def test_block_direct_reports_an_indefinite_block(gpu_lib):
