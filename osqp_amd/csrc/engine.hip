@@ -1857,9 +1857,11 @@ struct BdCtx {
   int     kc;
   const int *crow;         // [kc] the coupling rows of A
   const int *cidx;         // [m] position of a row in crow, -1 for the single-entry rows
+  const int *chuge;        // [kc] which folded huge row (Ctx::hrow) a coupling row is, -1: none
   double *cs, *cc;         // [kc] S t and Cinv S t
   double *cap;             // [kc][kc] capacitance matrix R^-1 + S B^-1 S', inverted in place (k_cap_invert)
-  double *t2;              // [n] scratch of the refresh
+  double *cap2;            // [kc][kc] the other copy of the pivot steps
+  double *wm;              // [16][n] scratch of the refresh: B^-1 S' for 16 coupling rows
 };
 
 __global__ void __launch_bounds__(TB) k_blk_invert(Ctx c, BdCtx bd) {
@@ -1921,7 +1923,7 @@ __global__ void __launch_bounds__(TB) k_blk_apply(Ctx c, BdCtx bd, const double 
     const int j = d.c0 + threadIdx.x;
     const bool on = (int)threadIdx.x < d.b;
     if (on) out[j] = y;
-    if (!bd.kc) for (int h = 0; h < c.nh; ++h) {
+    for (int h = 0; h < c.nh; ++h) {
       const double s = block_sum(on ? c.hcol[(size_t)h * c.n + j] * y : 0.0, red);
       if (threadIdx.x == 0) bd.part[(size_t)h * c.dP.nblk + db] = s;
     }
@@ -1968,12 +1970,27 @@ __global__ void __launch_bounds__(TB) k_blk_finish(Ctx c, BdCtx bd) {
 // The capacitance matrix is built at refresh from kc block passes (column r = S B^-1 S' e_r) and inverted by one workgroup
 // in place (k_cap_invert: Gauss-Jordan without pivoting, the matrix is positive definite when K is).
 #define CPL_MAX 512
-__global__ void __launch_bounds__(TB) k_cpl_dot(Ctx c, BdCtx bd, const double *x, double *out, int gated) {
+// out[blockIdx.y * ostride + r] = (row crow[r] of A) . x[blockIdx.y * xstride ...]; use_part: a folded huge row takes the per-block
+// partials the block pass left instead of walking its 50 000 entries (single right-hand side only)
+__global__ void __launch_bounds__(TB) k_cpl_dot(Ctx c, BdCtx bd, const double *x, double *out, int gated, int use_part, long long xstride, long long ostride, int nrhs) {
   if (gated) { const State *st = c.st; if (st->stalled || !st->run) return; }
+  if ((int)blockIdx.y >= nrhs) return;
   __shared__ double red[16];
-  const int i = bd.crow[blockIdx.x];
+  x += (size_t)blockIdx.y * xstride; out += (size_t)blockIdx.y * ostride;
+  const int i = bd.crow[blockIdx.x], h = use_part ? bd.chuge[blockIdx.x] : -1;
   double s = 0.0;
-  for (int k = c.A.rowptr[i] + (int)threadIdx.x; k < c.A.rowptr[i + 1]; k += TB) s += c.A.val[k] * x[c.A.col[k]];
+  if (h >= 0) {
+    for (int q = threadIdx.x; q < c.dP.nblk; q += TB) s += bd.part[(size_t)h * c.dP.nblk + q];
+  } else {
+    const int k0 = c.A.rowptr[i], k1 = c.A.rowptr[i + 1];
+    int k = k0 + (int)threadIdx.x;
+    for (; k + 3 * TB < k1; k += 4 * TB) {
+      const double v0 = c.A.val[k], v1 = c.A.val[k + TB], v2 = c.A.val[k + 2 * TB], v3 = c.A.val[k + 3 * TB];
+      const double x0 = x[c.A.col[k]], x1 = x[c.A.col[k + TB]], x2 = x[c.A.col[k + 2 * TB]], x3 = x[c.A.col[k + 3 * TB]];
+      s += v0 * x0; s += v1 * x1; s += v2 * x2; s += v3 * x3;
+    }
+    for (; k < k1; k += TB) s += c.A.val[k] * x[c.A.col[k]];
+  }
   s = block_sum(s, red);
   if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
@@ -1986,65 +2003,105 @@ __global__ void __launch_bounds__(TB) k_cpl_solve(Ctx c, BdCtx bd) {
   s = wave_sum(s);
   if (lane == 0) bd.cc[r] = s;
 }
-// entry j of S' v for a kc-vector v (unit >= 0: of S' e_unit): the A' part of row j of M, coupling rows only
-__device__ __forceinline__ double cpl_back_entry(const Ctx &c, const BdCtx &bd, const double *v, int unit, int j) {
+// entry j of S' v for a kc-vector v: the A' part of row j of M, coupling rows only
+__device__ __forceinline__ double cpl_back_entry(const Ctx &c, const BdCtx &bd, const double *v, int j) {
   double s = 0.0;
   for (int k = c.M.split[j]; k < c.M.rowptr[j + 1]; ++k) {
     const int q = bd.cidx[c.M.col[k] - c.n];
-    if (q < 0) continue;
-    if (unit >= 0) { if (q == unit) s += c.M.val[k]; }
-    else s += c.M.val[k] * v[q];
+    if (q >= 0) s += c.M.val[k] * v[q];
   }
   return s;
 }
-// fin: x~ = x~0 + t - B^-1 S' c, the solve is complete.  Otherwise (refresh): out = B^-1 S' e_unit.
-__global__ void __launch_bounds__(TB) k_blk_apply_back(Ctx c, BdCtx bd, int unit, double *out, int fin) {
+// x~ = x~0 + t - B^-1 S' c, the solve is complete
+__global__ void __launch_bounds__(TB) k_blk_apply_back(Ctx c, BdCtx bd) {
   State *st = c.st;
-  if (fin && (st->stalled || !st->run)) return;
+  if (st->stalled || !st->run) return;
   __shared__ double scratch[5 * DENSE_MAX];
   const DenseP inv{c.dP.nblk, c.dP.blk, bd.binv};
   for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
     const DenseBlk d = c.dP.blk[db];
-    const double y = dense_block_mv_x(inv, d, [&](int j) { return cpl_back_entry(c, bd, bd.cc, unit, j); }, scratch);
+    const double y = dense_block_mv_x(inv, d, [&](int j) { return cpl_back_entry(c, bd, bd.cc, j); }, scratch);
     const int j = d.c0 + threadIdx.x;
-    if ((int)threadIdx.x < d.b) { if (fin) c.va[j] = c.vx[j] + (bd.t[j] - y); else out[j] = y; }
+    if ((int)threadIdx.x < d.b) c.va[j] = c.vx[j] + (bd.t[j] - y);
     __syncthreads();
   }
-  if (fin && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->iters[0] = 1; st->iters[1] = 0; st->done = 1;
     if (*bd.flag) st->neg_curv = 1;
   }
 }
-// cap <- (cap + R^-1)^-1 in place, one workgroup: thread <-> column j and the rows i0, i0 + 2, ... as k_blk_invert, the matrix in
-// global memory (2 MB at 512 rows: L2), the pivot row and column of each step in LDS
-__global__ void __launch_bounds__(2 * CPL_MAX) k_cap_invert(Ctx c, BdCtx bd) {
-  __shared__ double colp[CPL_MAX], rowp[CPL_MAX];
-  const int kc = bd.kc, t = threadIdx.x, j = t & (CPL_MAX - 1), i0 = t / CPL_MAX;
-  double *C = bd.cap;
-  if (t < kc) {
-    const double rho = c.rho[bd.crow[t]];
-    if (!(rho > 0.0)) atomicOr(bd.flag, 1);
-    C[(size_t)t * kc + t] += 1.0 / rho;
-  }
-  __syncthreads();
-  for (int p = 0; p < kc; ++p) {
-    if (t < kc) { colp[t] = C[(size_t)t * kc + p]; rowp[t] = C[(size_t)p * kc + t]; }
+// Refresh: W_g = B^-1 S_g' for a group of 16 coupling rows [r0, r0 + 16) at once -- the one place of this path where a block
+// meets several vectors, so the product runs on the matrix cores: v_mfma_f64_16x16x4_f64, D (16 rows of the block x 16
+// right-hand sides) += A (16 x 4 tile of the inverse block, read transposed: the block is symmetric, so 4 rows x 16
+// contiguous doubles per wave load) x B (4 x 16 tile of S_g' from LDS).  Wavefront w owns rows [32 w, 32 w + 32) of the block.
+// One pass over the 50 MB of inverse blocks serves 16 columns of the capacitance matrix (the VALU kernel above: one).
+// out: [16][n].
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(TB) k_blk_apply_multi(Ctx c, BdCtx bd, int r0, double *out) {
+  __shared__ double xl[DENSE_MAX * 16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  static_assert(TB == 256 && DENSE_MAX == 128, "four wavefronts x two 16-row tiles cover a block");
+  for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
+    const DenseBlk d = c.dP.blk[db];
+    const double *dv = bd.binv + d.off;
+    double a[2][DENSE_MAX / 4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kt = 0; kt < DENSE_MAX / 4; ++kt) {
+        const int k = 4 * kt + lk, i = 32 * w + 16 * t + li;
+        a[t][kt] = (k < d.b && i < d.b) ? dv[(size_t)k * d.pitch + i] : 0.0;
+      }
+    for (int q = threadIdx.x; q < DENSE_MAX * 16; q += TB) xl[q] = 0.0;
     __syncthreads();
-    const double piv = rowp[p];
-    if (!(piv > 0.0) && t == 0) atomicOr(bd.flag, 1);
-    const double inv = 1.0 / piv;
-    if (j < kc) {
-      const double rj = rowp[j] * inv;
-      for (int i = i0; i < kc; i += 2) {
-        double v;
-        if (i == p) v = (j == p) ? inv : rj;
-        else if (j == p) v = -colp[i] * inv;
-        else v = C[(size_t)i * kc + j] - colp[i] * rj;
-        C[(size_t)i * kc + j] = v;
+    if ((int)threadIdx.x < d.b) {
+      const int j = d.c0 + threadIdx.x;
+      for (int k = c.M.split[j]; k < c.M.rowptr[j + 1]; ++k) {
+        const int q = bd.cidx[c.M.col[k] - c.n] - r0;
+        if (q >= 0 && q < 16) xl[threadIdx.x * 16 + q] = c.M.val[k];
       }
     }
     __syncthreads();
+    mfma_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kt = 0; kt < DENSE_MAX / 4; ++kt) {
+      const double bv = xl[(4 * kt + lk) * 16 + li];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][kt], bv, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][kt], bv, acc1, 0, 0, 0);
+    }
+    // D[row = lk + 4 r][col = li]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i0 = 32 * w + lk + 4 * r, i1 = i0 + 16;
+      if (i0 < d.b) out[(size_t)li * c.n + d.c0 + i0] = acc0[r];
+      if (i1 < d.b) out[(size_t)li * c.n + d.c0 + i1] = acc1[r];
+    }
+    __syncthreads();
   }
+}
+// cap <- (cap + R^-1)^-1: Gauss-Jordan without pivoting (the matrix is positive definite when K is), one launch per pivot over
+// the whole machine, from one copy of the matrix into the other (no element is read after it was rewritten).  One workgroup
+// walking the 2 MB in global memory took 61 us per pivot (31 ms at 501 rows); a launch takes 3.
+__global__ void __launch_bounds__(TB) k_cap_diag(Ctx c, BdCtx bd) {
+  const int r = blockIdx.x * TB + threadIdx.x;
+  if (r >= bd.kc) return;
+  const double rho = c.rho[bd.crow[r]];
+  if (!(rho > 0.0)) atomicOr(bd.flag, 1);
+  bd.cap[(size_t)r * bd.kc + r] += 1.0 / rho;
+}
+__global__ void __launch_bounds__(TB) k_cap_step(BdCtx bd, const double *src, double *dst, int p) {
+  const int kc = bd.kc;
+  const long long e = (long long)blockIdx.x * TB + threadIdx.x;
+  if (e >= (long long)kc * kc) return;
+  const int i = (int)(e / kc), j = (int)(e - (long long)i * kc);
+  const double piv = src[(size_t)p * kc + p];
+  if (e == 0 && !(piv > 0.0)) atomicOr(bd.flag, 1);
+  const double inv = 1.0 / piv, rj = src[(size_t)p * kc + j] * inv, ci = src[(size_t)i * kc + p];
+  double v;
+  if (i == p) v = (j == p) ? inv : rj;
+  else if (j == p) v = -ci * inv;
+  else v = src[e] - ci * rj;
+  dst[e] = v;
 }
 
 // ---------------------------------------------------------------------------
@@ -2769,9 +2826,9 @@ static void launch_resident(hipeng *e) {
     const int gb = std::max(1, std::min(1024, e->c.dP.nblk));
     hipLaunchKernelGGL(k_blk_apply, dim3(gb), dim3(TB), 0, e->stream, e->c, e->bd, (const double *)e->c.init_r, e->bd.t, 1);
     if (e->bd.kc) {
-      hipLaunchKernelGGL(k_cpl_dot, dim3(e->bd.kc), dim3(TB), 0, e->stream, e->c, e->bd, (const double *)e->bd.t, e->bd.cs, 1);
+      hipLaunchKernelGGL(k_cpl_dot, dim3(e->bd.kc), dim3(TB), 0, e->stream, e->c, e->bd, (const double *)e->bd.t, e->bd.cs, 1, 1, 0ll, 0ll, 1);
       hipLaunchKernelGGL(k_cpl_solve, dim3((e->bd.kc + TB / 64 - 1) / (TB / 64)), dim3(TB), 0, e->stream, e->c, e->bd);
-      hipLaunchKernelGGL(k_blk_apply_back, dim3(gb), dim3(TB), 0, e->stream, e->c, e->bd, -1, (double *)nullptr, 1);
+      hipLaunchKernelGGL(k_blk_apply_back, dim3(gb), dim3(TB), 0, e->stream, e->c, e->bd);
       return;
     }
     hipLaunchKernelGGL(k_blk_finish, dim3(std::max(1, std::min(256, (e->n + TB - 1) / TB))), dim3(TB), 0, e->stream, e->c, e->bd);
@@ -3115,16 +3172,19 @@ static int build_blockdirect(hipeng *e) {
   if (!plain && !blocks_coupled_eligible(e, crows)) return 0;
   BdCtx bd{};
   if (!plain) {
-    int *d_crow = nullptr, *d_cidx = nullptr;
+    int *d_crow = nullptr, *d_cidx = nullptr, *d_chuge = nullptr;
     const size_t kc = crows.size();
+    std::vector<int> chuge(kc, -1);
+    for (size_t r = 0; r < kc; r++) for (size_t h = 0; h < e->hrows.size(); h++) if (e->hrows[h] == crows[r]) chuge[r] = (int)h;
     std::vector<int> cidx((size_t)std::max(1, e->m), -1);
     for (size_t r = 0; r < kc; r++) cidx[crows[r]] = (int)r;
-    if (dev_alloc(e, &d_crow, kc) || dev_alloc(e, &d_cidx, cidx.size()) || dev_alloc(e, &bd.cs, kc) || dev_alloc(e, &bd.cc, kc) ||
-        dev_alloc(e, &bd.cap, kc * kc) || dev_alloc(e, &bd.t2, (size_t)e->n)) return HIPENG_ERR_HIP;
+    if (dev_alloc(e, &d_crow, kc) || dev_alloc(e, &d_chuge, kc) || dev_alloc(e, &d_cidx, cidx.size()) || dev_alloc(e, &bd.cs, kc) || dev_alloc(e, &bd.cc, kc) ||
+        dev_alloc(e, &bd.cap, kc * kc) || dev_alloc(e, &bd.cap2, kc * kc) || dev_alloc(e, &bd.wm, (size_t)16 * e->n)) return HIPENG_ERR_HIP;
     HIPCHK(hipMemcpyAsync(d_crow, crows.data(), kc * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d_cidx, cidx.data(), cidx.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d_chuge, chuge.data(), kc * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));          // (the sources are locals)
-    bd.kc = (int)kc; bd.crow = d_crow; bd.cidx = d_cidx;
+    bd.kc = (int)kc; bd.crow = d_crow; bd.cidx = d_cidx; bd.chuge = d_chuge;
   }
   const size_t nd = e->dP_src.size(), n = (size_t)e->n, nb = e->dP_blks.size();
   if (dev_alloc(e, &bd.binv, nd) || dev_alloc(e, &bd.t, n) || dev_alloc(e, &bd.wh, (size_t)MAX_HUGE_FOLD * n) ||
@@ -3150,13 +3210,19 @@ static int blk_refresh(hipeng *e) {
   for (const DenseBlk &d : e->dP_blks) bmax = std::max(bmax, d.b);
   hipLaunchKernelGGL(k_blk_invert, dim3(std::min(nb, 1024)), dim3(TB), (size_t)bmax * bmax * sizeof(double), e->stream, e->c, e->bd);
   if (e->bd.kc) {
-    // capacitance matrix, row r = S (B^-1 S' e_r): a block pass and kc row dots per coupling row, all on the stream
+    // capacitance matrix, rows r0 .. r0 + 15 = S (B^-1 S_g')': one block pass on the matrix cores and 16 kc row dots per group,
+    // then the diagonal and kc pivot steps; everything on the stream
     const int kc = e->bd.kc;
-    for (int r = 0; r < kc; r++) {
-      hipLaunchKernelGGL(k_blk_apply_back, dim3(std::min(nb, 1024)), dim3(TB), 0, e->stream, e->c, e->bd, r, e->bd.t2, 0);
-      hipLaunchKernelGGL(k_cpl_dot, dim3(kc), dim3(TB), 0, e->stream, e->c, e->bd, (const double *)e->bd.t2, e->bd.cap + (size_t)r * kc, 0);
+    for (int r0 = 0; r0 < kc; r0 += 16) {
+      hipLaunchKernelGGL(k_blk_apply_multi, dim3(std::min(nb, 1024)), dim3(TB), 0, e->stream, e->c, e->bd, r0, e->bd.wm);
+      hipLaunchKernelGGL(k_cpl_dot, dim3(kc, 16), dim3(TB), 0, e->stream, e->c, e->bd, (const double *)e->bd.wm, e->bd.cap + (size_t)r0 * kc, 0, 0,
+                         (long long)n, (long long)kc, std::min(16, kc - r0));
     }
-    hipLaunchKernelGGL(k_cap_invert, dim3(1), dim3(2 * CPL_MAX), 0, e->stream, e->c, e->bd);
+    hipLaunchKernelGGL(k_cap_diag, dim3((kc + TB - 1) / TB), dim3(TB), 0, e->stream, e->c, e->bd);
+    double *src = e->bd.cap, *dst = e->bd.cap2;
+    const unsigned gs = (unsigned)(((long long)kc * kc + TB - 1) / TB);
+    for (int p = 0; p < kc; p++) { hipLaunchKernelGGL(k_cap_step, dim3(gs), dim3(TB), 0, e->stream, e->bd, (const double *)src, dst, p); std::swap(src, dst); }
+    if (src != e->bd.cap) HIPCHK(hipMemcpyAsync(e->bd.cap, src, (size_t)kc * kc * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
