@@ -245,7 +245,45 @@ def other_configs(eps):
         except Exception:
             pass
         del s
+    out["config5_plus_500_sector_rows"] = config5_sector_rows(eps)
     return out
+
+
+def config5_sector_rows(eps, rows=500):
+    """SURVEY C5 "optionally + 500 sparse sector rows": rows of A that tie variables of different blocks together.  The
+    block-direct solve carries every multi-entry row of A as the low-rank term (coupled form); beside it the same
+    problem on the launch-per-step PCG kernels (OSQP_AMD_BLOCK_COUPLED_MAX=0), which is where it ran before."""
+    import osqp_amd
+    from osqp_amd.problems import portfolio_qp
+    L = osqp_amd.lib()
+    L.hipeng_resident_info.restype = C.c_int
+    L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    pb = portfolio_qp(sector_rows=rows)
+    res = {}
+    ref = None
+    for key, cap in (("block_direct_coupled", None), ("launch_per_step_pcg", "0")):
+        if cap is not None:
+            os.environ["OSQP_AMD_BLOCK_COUPLED_MAX"] = cap
+        try:
+            t0 = time.perf_counter(); s = osqp_amd.OSQP().setup(**pb, eps_abs=eps, eps_rel=eps); ts = time.perf_counter() - t0
+        finally:
+            os.environ.pop("OSQP_AMD_BLOCK_COUPLED_MAX", None)
+        info = (C.c_longlong * 16)()
+        L.hipeng_resident_info(s.engine(), info)
+        t0 = time.perf_counter(); r = s.solve(); tv = time.perf_counter() - t0
+        st = s.stats()
+        t0 = time.perf_counter(); s.update_rho(0.2); tr = time.perf_counter() - t0
+        res[key] = dict(setup_s=round(ts, 3), status=r.info.status, admm_iters=int(r.info.iter), solve_s=round(tv, 4),
+                        admm_iters_per_s=round(r.info.iter / tv, 1), pcg_iters_per_admm_iter=round(st["pcg_iters_total"] / max(1, r.info.iter), 1),
+                        osqp_update_rho_ms=round(1e3 * tr, 2), form=int(info[9]), coupling_rows=int(info[15]))
+        if ref is None:
+            ref = r
+        else:
+            res["max_abs_dx_between_the_two"] = float(np.abs(r.x - ref.x).max())
+            res["same_iteration_count"] = bool(r.info.iter == ref.info.iter)
+        del s
+    res["n"], res["m"], res["sector_rows"] = int(pb["P"].shape[0]), int(pb["A"].shape[0]), rows
+    return res
 
 
 def _recorded(cfg):

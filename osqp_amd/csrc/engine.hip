@@ -1852,6 +1852,7 @@ struct BdCtx {
   double *cinv;            // [nh][nh] (R_h^-1 + A_h W)^-1
   double *part;            // [MAX_HUGE_FOLD][nblk] partials of A_h t per block
   int    *flag;            // [0] a pivot was not positive
+  int     fin_dots;        // the kernel that writes x~ also leaves the folded huge rows' partials of A x~ for k_admm_finalize (no k_huge_dot launch)
   // coupled form (kc > 0): EVERY row of A with two or more entries -- sector rows, the budget row, whatever their length -- is a
   // term of the low-rank part; nothing of W is stored (see k_cpl_dot)
   int     kc;
@@ -1896,12 +1897,22 @@ __global__ void __launch_bounds__(TB) k_blk_invert(Ctx c, BdCtx bd) {
       const double inv = 1.0 / piv;
       if (j < b) {
         const double rj = rowp[j] * inv;              // row p of the result (j != p)
-        for (int i = i0; i < b; i += 2) {
-          double v;
-          if (i == p) v = (j == p) ? inv : rj;
-          else if (j == p) v = -colp[i] * inv;
-          else v = bl[i * b + j] - colp[i] * rj;
-          bl[i * b + j] = v;
+        // eight rows at a time: their LDS reads are in flight together (one by one, read -> fma -> write of each element
+        // waited for the one before: 7.6 us per pivot, 2.0 ms for the 400 blocks of config 5)
+        for (int ib = i0; ib < b; ib += 16) {
+          double cur[8], cp[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int i = ib + 2 * u; if (i < b) { cur[u] = bl[i * b + j]; cp[u] = colp[i]; } else { cur[u] = 0.0; cp[u] = 0.0; } }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = ib + 2 * u;
+            if (i >= b) continue;
+            double v;
+            if (i == p) v = (j == p) ? inv : rj;
+            else if (j == p) v = -cp[u] * inv;
+            else v = cur[u] - cp[u] * rj;
+            bl[i * b + j] = v;
+          }
         }
       }
       __syncthreads();
@@ -1931,6 +1942,16 @@ __global__ void __launch_bounds__(TB) k_blk_apply(Ctx c, BdCtx bd, const double 
   }
 }
 
+// (A x~)_h of the folded huge rows for k_admm_finalize, by the kernel that has just written x~: this workgroup's partial into its
+// slot of Ctx::part_h, zeros into the slots no workgroup of this launch owns (k_huge_dot, which other paths run, fills all gridA)
+__device__ __forceinline__ void fin_huge_partials(const Ctx &c, const double *hd, double *red) {
+  for (int h = 0; h < c.nh; ++h) {
+    const double s = block_sum(hd[h], red);
+    if (threadIdx.x == 0)
+      for (int slot = blockIdx.x; slot < c.gridA; slot += gridDim.x) c.part_h[(size_t)h * c.gridA + slot] = slot == (int)blockIdx.x ? s : 0.0;
+  }
+}
+
 // x~ = x~0 + t - W c with c = Cinv (A_h t); the linear solve is complete (one "PCG iteration" in the statistics)
 __global__ void __launch_bounds__(TB) k_blk_finish(Ctx c, BdCtx bd) {
   State *st = c.st;
@@ -1950,11 +1971,16 @@ __global__ void __launch_bounds__(TB) k_blk_finish(Ctx c, BdCtx bd) {
     cs[threadIdx.x] = (int)threadIdx.x < c.nh ? v : 0.0;
   }
   __syncthreads();
+  static_assert(MAX_HUGE_FOLD == 4, "initialisers below");
+  double hd[MAX_HUGE_FOLD] = {0.0, 0.0, 0.0, 0.0};
   for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
     double v = bd.t[j];
     for (int h = 0; h < c.nh; ++h) v -= bd.wh[(size_t)h * c.n + j] * cs[h];
-    c.va[j] = c.vx[j] + v;
+    const double xt = c.vx[j] + v;
+    c.va[j] = xt;
+    if (bd.fin_dots) for (int h = 0; h < c.nh; ++h) hd[h] += c.hcol[(size_t)h * c.n + j] * xt;
   }
+  if (bd.fin_dots) fin_huge_partials(c, hd, red);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->iters[0] = 1; st->iters[1] = 0; st->done = 1;
     if (*bd.flag) st->neg_curv = 1;
@@ -2017,14 +2043,21 @@ __global__ void __launch_bounds__(TB) k_blk_apply_back(Ctx c, BdCtx bd) {
   State *st = c.st;
   if (st->stalled || !st->run) return;
   __shared__ double scratch[5 * DENSE_MAX];
+  __shared__ double red[16];
   const DenseP inv{c.dP.nblk, c.dP.blk, bd.binv};
+  double hd[MAX_HUGE_FOLD] = {0.0, 0.0, 0.0, 0.0};
   for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
     const DenseBlk d = c.dP.blk[db];
     const double y = dense_block_mv_x(inv, d, [&](int j) { return cpl_back_entry(c, bd, bd.cc, j); }, scratch);
     const int j = d.c0 + threadIdx.x;
-    if ((int)threadIdx.x < d.b) c.va[j] = c.vx[j] + (bd.t[j] - y);
+    if ((int)threadIdx.x < d.b) {
+      const double xt = c.vx[j] + (bd.t[j] - y);
+      c.va[j] = xt;
+      if (bd.fin_dots) for (int h = 0; h < c.nh; ++h) hd[h] += c.hcol[(size_t)h * c.n + j] * xt;
+    }
     __syncthreads();
   }
+  if (bd.fin_dots) fin_huge_partials(c, hd, red);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->iters[0] = 1; st->iters[1] = 0; st->done = 1;
     if (*bd.flag) st->neg_curv = 1;
@@ -3193,6 +3226,13 @@ static int build_blockdirect(hipeng *e) {
     (void)hipGetLastError();
     return 0;                        // not an error: the block-resident PCG takes over
   }
+  {
+    // A x~ of the folded huge rows from the kernel that writes x~ (instead of a k_huge_dot launch per ADMM iteration): every
+    // huge row folded, and that kernel's grid within the gridA partial slots k_admm_finalize sums
+    const int fin_grid = bd.kc ? std::max(1, std::min(1024, (int)nb)) : std::max(1, std::min(256, (e->n + TB - 1) / TB));
+    bd.fin_dots = !e->hrows.empty() && (int)e->A.blk.size() - e->A.nwave == (int)e->hrows.size() && fin_grid <= e->c.gridA;
+    if (const char *x = getenv("OSQP_AMD_BLOCK_FIN_DOTS")) bd.fin_dots = bd.fin_dots && atoi(x) != 0;
+  }
   e->bd = bd;
   // the solve kernels read the residual as a plain n-vector
   e->c.init_r = e->c.r; e->c.init_stride = 1;
@@ -3780,7 +3820,8 @@ static int get_graph(hipeng *e, int K, int R, int spec_lo, hipGraphExec_t *out) 
     if (K == 0) launch_resident(e);                   // the whole linear solve in one launch (K in registers)
     else { launch_cg_A(e, -1, 8); launch_cg_B(e, -1, 0); }   // operator apply on u0 (+ first convergence test), then w0 and the first dots
     for (int it = 0; it < K; it++) launch_pcg_iter(e, it, 0, spec_lo);
-    if (e->c.A.nblk > e->c.A.nwave) hipLaunchKernelGGL(k_huge_dot, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, (const double *)nullptr, 0);
+    if (e->c.A.nblk > e->c.A.nwave && !(K == 0 && e->res_kind == 3 && e->bd.fin_dots))      // (block-direct: the kernel that wrote x~ left the partials)
+      hipLaunchKernelGGL(k_huge_dot, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, (const double *)nullptr, 0);
     hipLaunchKernelGGL(k_admm_finalize, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c);
   }
   HIPCHK(hipStreamEndCapture(e->stream, &g));

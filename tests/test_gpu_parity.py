@@ -389,7 +389,7 @@ def test_full_size_config2_matches_oracle_golden(gpu_lib):
     assert abs(r.info.dua_res - gi["dua"]) <= 1e-4 * gi["dua"] + 1e-9
 
 
-@pytest.mark.parametrize("cfg", ["config5", "config3"])
+@pytest.mark.parametrize("cfg", ["config5", "config5s", "config3"])
 def test_full_size_config3_config5_match_oracle_golden(gpu_lib, cfg):
     """BASELINE configs 5 (portfolio, n = 50000: 400 dense 125x125 blocks of P through the dense
     block kernels, a 50 000-entry budget row through the sliced huge-row path) and 3 (Lasso,
@@ -398,14 +398,16 @@ def test_full_size_config3_config5_match_oracle_golden(gpu_lib, cfg):
     Lasso run took the oracle 77 s to factorise and 282 s to solve): same iteration count
     (325 / 1875) and rho updates, x, y and the objective within 1e-6 relative -- at the default
     engine options (both families carry equality rows, for which osqp_solve tightens the PCG stop
-    to 1e-12 by itself; at a plain 1e-10 they agreed to 1e-4 only)."""
+    to 1e-12 by itself; at a plain 1e-10 they agreed to 1e-4 only).  config5s: config 5 + 500 sparse sector rows
+    (`tools/make_config5_golden.py 500`: 2525 iterations, 103 s on the CPU), solved by the coupled
+    block-direct form."""
     import json, os
     import osqp_amd
     from conftest import GOLDEN
     from osqp_amd.problems import portfolio_qp, lasso_qp
     g = json.load(open(os.path.join(GOLDEN, cfg + "_oracle.json")))
-    if cfg == "config5":
-        pb, kw, step = portfolio_qp(), dict(adaptive_rho_interval=100), 50
+    if cfg in ("config5", "config5s"):
+        pb, kw, step = portfolio_qp(sector_rows=500 if cfg == "config5s" else 0), dict(adaptive_rho_interval=100), 50
     else:
         pb, kw, step = {k: v for k, v in lasso_qp().items() if k in "PqAlu"}, {}, 20
     assert osqp_amd.engine_options()["pcg_eps_rel"] == 1e-9
@@ -420,7 +422,7 @@ def test_full_size_config3_config5_match_oracle_golden(gpu_lib, cfg):
     assert np.abs(r.y[::step] - ys).max() <= 1e-6 * max(1.0, g["y_inf"])
     assert s.stats()["pcg_forced"] == 0
     # config 5 runs its linear solves as block-direct solves (k_blk_apply / k_blk_finish), config 3 fits no resident form
-    assert s.stats()["resident"] == (1 if cfg == "config5" else 0)
+    assert s.stats()["resident"] == (1 if cfg.startswith("config5") else 0)
 
 
 def test_non_cvx_golden(gpu_lib):
