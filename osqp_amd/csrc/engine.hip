@@ -388,11 +388,18 @@ __device__ __forceinline__ double wave_row_dot(const DevMat &Mx, int ka, int kb,
 // (<= 32 rows per wavefront); the four partial vectors meet in LDS.  No index loads, no gathers.
 // Returns y_r for r = threadIdx.x < b (0 otherwise); scratch: 5*DENSE_MAX doubles, x_b is left
 // in scratch[4*DENSE_MAX ...].  Ends with a barrier; the caller adds one before reusing scratch.
-template <class XL>
+// EARLY: the input element comes out of a chain of dependent loads (k_blk_apply_back).  vmcnt completes in order, so behind the
+// 32 block loads every link of the chain would wait for all of them; the chain runs first, alone, and is waited for.
+template <bool EARLY = false, class XL>
 __device__ __forceinline__ double dense_block_mv_x(const DenseP &dP, const DenseBlk d, XL xload, double *scratch) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const double2 *dv = reinterpret_cast<const double2 *>(dP.val + d.off);
   const int hp = d.pitch >> 1;
+  double xe = 0.0;
+  if (EARLY) {
+    if ((int)threadIdx.x < d.b) xe = xload(d.c0 + (int)threadIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   double2 v[DENSE_MAX / 4];
 #pragma unroll
   for (int q = 0; q < DENSE_MAX / 4; ++q) {
@@ -400,7 +407,7 @@ __device__ __forceinline__ double dense_block_mv_x(const DenseP &dP, const Dense
     v[q] = (j < d.b && lane < hp) ? dv[(size_t)j * hp + lane] : double2{0.0, 0.0};
   }
   double *xl = scratch + 4 * DENSE_MAX;
-  if ((int)threadIdx.x < DENSE_MAX) xl[threadIdx.x] = (int)threadIdx.x < d.b ? xload(d.c0 + (int)threadIdx.x) : 0.0;
+  if ((int)threadIdx.x < DENSE_MAX) xl[threadIdx.x] = EARLY ? xe : ((int)threadIdx.x < d.b ? xload(d.c0 + (int)threadIdx.x) : 0.0);
   __syncthreads();
   double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -414,7 +421,7 @@ __device__ __forceinline__ double dense_block_mv_x(const DenseP &dP, const Dense
   return r < d.b ? (scratch[r] + scratch[DENSE_MAX + r]) + (scratch[2 * DENSE_MAX + r] + scratch[3 * DENSE_MAX + r]) : 0.0;
 }
 __device__ __forceinline__ double dense_block_mv(const DenseP &dP, const DenseBlk d, const double *x, double *scratch) {
-  return dense_block_mv_x(dP, d, [x](int j) { return x[j]; }, scratch);
+  return dense_block_mv_x<false>(dP, d, [x](int j) { return x[j]; }, scratch);
 }
 
 #define LDS_DECL(NV)                                   \
@@ -1859,24 +1866,28 @@ struct BdCtx {
   const int *crow;         // [kc] the coupling rows of A
   const int *cidx;         // [m] position of a row in crow, -1 for the single-entry rows
   const int *chuge;        // [kc] which folded huge row (Ctx::hrow) a coupling row is, -1: none
+  const int *cbptr;        // [n + 1] / cbent: per column j the entries of the coupling rows, {position in crow, slot of the value in M.val}
+  const int2 *cbent;
   double *cs, *cc;         // [kc] S t and Cinv S t
   double *cap;             // [kc][kc] capacitance matrix R^-1 + S B^-1 S', inverted in place (k_cap_invert)
   double *cap2;            // [kc][kc] the other copy of the pivot steps
   double *wm;              // [16][n] scratch of the refresh: B^-1 S' for 16 coupling rows
 };
 
-__global__ void __launch_bounds__(TB) k_blk_invert(Ctx c, BdCtx bd) {
+#define INV_TB 1024
+__global__ void __launch_bounds__(INV_TB) k_blk_invert(Ctx c, BdCtx bd) {
   extern __shared__ __attribute__((aligned(16))) double bl[];       // b x b, row pitch b
   __shared__ double colp[DENSE_MAX], rowp[DENSE_MAX];
   const double sigma = c.prm->sigma;
-  // thread -> column j and the rows i = i0, i0 + 2, ... (no index arithmetic in the sweep: a division per element
-  // made this kernel 2.85 ms for the 400 blocks of config 5)
+  // thread -> column j and the rows i = i0, i0 + 8, ... (no index arithmetic in the sweep: a division per element made this
+  // kernel 2.85 ms for the 400 blocks of config 5; with 256 threads -- one wavefront per SIMD, nothing to hide the LDS round trips
+  // of the sweep behind -- it was 1.9 ms)
+  constexpr int RS = INV_TB / DENSE_MAX, RU = DENSE_MAX / RS;        // row step 8, up to 16 rows per thread
   const int t = threadIdx.x, j = t & (DENSE_MAX - 1), i0 = t / DENSE_MAX;
-  static_assert(TB == 2 * DENSE_MAX, "two rows per sweep step");
   for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
     const DenseBlk d = c.dP.blk[db];
     const int b = d.b;
-    if (j < b) for (int i = i0; i < b; i += 2) bl[i * b + j] = c.dP.val[d.off + (size_t)i * d.pitch + j];
+    if (j < b) for (int i = i0; i < b; i += RS) bl[i * b + j] = c.dP.val[d.off + (size_t)i * d.pitch + j];
     __syncthreads();
     if (t < b) {                       // diagonal: sigma + the single-entry rows of A at this column (the huge rows are the low-rank part)
       const int jj = d.c0 + t;
@@ -1897,27 +1908,23 @@ __global__ void __launch_bounds__(TB) k_blk_invert(Ctx c, BdCtx bd) {
       const double inv = 1.0 / piv;
       if (j < b) {
         const double rj = rowp[j] * inv;              // row p of the result (j != p)
-        // eight rows at a time: their LDS reads are in flight together (one by one, read -> fma -> write of each element
-        // waited for the one before: 7.6 us per pivot, 2.0 ms for the 400 blocks of config 5)
-        for (int ib = i0; ib < b; ib += 16) {
-          double cur[8], cp[8];
+        double cur[RU], cp[RU];                       // all rows of the thread: their LDS reads are in flight together
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const int i = ib + 2 * u; if (i < b) { cur[u] = bl[i * b + j]; cp[u] = colp[i]; } else { cur[u] = 0.0; cp[u] = 0.0; } }
+        for (int u = 0; u < RU; ++u) { const int i = i0 + RS * u; if (i < b) { cur[u] = bl[i * b + j]; cp[u] = colp[i]; } else { cur[u] = 0.0; cp[u] = 0.0; } }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int i = ib + 2 * u;
-            if (i >= b) continue;
-            double v;
-            if (i == p) v = (j == p) ? inv : rj;
-            else if (j == p) v = -cp[u] * inv;
-            else v = cur[u] - cp[u] * rj;
-            bl[i * b + j] = v;
-          }
+        for (int u = 0; u < RU; ++u) {
+          const int i = i0 + RS * u;
+          if (i >= b) continue;
+          double v;
+          if (i == p) v = (j == p) ? inv : rj;
+          else if (j == p) v = -cp[u] * inv;
+          else v = cur[u] - cp[u] * rj;
+          bl[i * b + j] = v;
         }
       }
       __syncthreads();
     }
-    if (j < d.pitch) for (int i = i0; i < b; i += 2) bd.binv[d.off + (size_t)i * d.pitch + j] = j < b ? bl[i * b + j] : 0.0;
+    if (j < d.pitch) for (int i = i0; i < b; i += RS) bd.binv[d.off + (size_t)i * d.pitch + j] = j < b ? bl[i * b + j] : 0.0;
     __syncthreads();
   }
 }
@@ -2029,13 +2036,11 @@ __global__ void __launch_bounds__(TB) k_cpl_solve(Ctx c, BdCtx bd) {
   s = wave_sum(s);
   if (lane == 0) bd.cc[r] = s;
 }
-// entry j of S' v for a kc-vector v: the A' part of row j of M, coupling rows only
+// entry j of S' v for a kc-vector v: the coupling rows' entries of column j as (position in crow, slot of the value in M), a list
+// of their own (through M itself: split/rowptr -> col -> cidx -> v, four dependent loads; here three)
 __device__ __forceinline__ double cpl_back_entry(const Ctx &c, const BdCtx &bd, const double *v, int j) {
   double s = 0.0;
-  for (int k = c.M.split[j]; k < c.M.rowptr[j + 1]; ++k) {
-    const int q = bd.cidx[c.M.col[k] - c.n];
-    if (q >= 0) s += c.M.val[k] * v[q];
-  }
+  for (int k = bd.cbptr[j]; k < bd.cbptr[j + 1]; ++k) { const int2 e = bd.cbent[k]; s += c.M.val[e.y] * v[e.x]; }
   return s;
 }
 // x~ = x~0 + t - B^-1 S' c, the solve is complete
@@ -2048,7 +2053,7 @@ __global__ void __launch_bounds__(TB) k_blk_apply_back(Ctx c, BdCtx bd) {
   double hd[MAX_HUGE_FOLD] = {0.0, 0.0, 0.0, 0.0};
   for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
     const DenseBlk d = c.dP.blk[db];
-    const double y = dense_block_mv_x(inv, d, [&](int j) { return cpl_back_entry(c, bd, bd.cc, j); }, scratch);
+    const double y = dense_block_mv_x<true>(inv, d, [&](int j) { return cpl_back_entry(c, bd, bd.cc, j); }, scratch);
     const int j = d.c0 + threadIdx.x;
     if ((int)threadIdx.x < d.b) {
       const double xt = c.vx[j] + (bd.t[j] - y);
@@ -3218,6 +3223,20 @@ static int build_blockdirect(hipeng *e) {
     HIPCHK(hipMemcpyAsync(d_chuge, chuge.data(), kc * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));          // (the sources are locals)
     bd.kc = (int)kc; bd.crow = d_crow; bd.cidx = d_cidx; bd.chuge = d_chuge;
+    {
+      std::vector<int> cbptr((size_t)e->n + 1, 0);
+      std::vector<int2> cbent;
+      for (int j = 0; j < e->n; j++) {
+        for (int k = e->M.split[j]; k < e->M.rowptr[j + 1]; k++) { const int q = cidx[e->M.col[k] - e->n]; if (q >= 0) cbent.push_back(int2{q, k}); }
+        cbptr[j + 1] = (int)cbent.size();
+      }
+      int *d_ptr = nullptr; int2 *d_ent = nullptr;
+      if (dev_alloc(e, &d_ptr, cbptr.size()) || dev_alloc(e, &d_ent, std::max<size_t>(1, cbent.size()))) return HIPENG_ERR_HIP;
+      HIPCHK(hipMemcpyAsync(d_ptr, cbptr.data(), cbptr.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+      if (!cbent.empty()) HIPCHK(hipMemcpyAsync(d_ent, cbent.data(), cbent.size() * sizeof(int2), hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      bd.cbptr = d_ptr; bd.cbent = d_ent;
+    }
   }
   const size_t nd = e->dP_src.size(), n = (size_t)e->n, nb = e->dP_blks.size();
   if (dev_alloc(e, &bd.binv, nd) || dev_alloc(e, &bd.t, n) || dev_alloc(e, &bd.wh, (size_t)MAX_HUGE_FOLD * n) ||
@@ -3248,7 +3267,7 @@ static int blk_refresh(hipeng *e) {
   HIPCHK(hipMemsetAsync(e->bd.flag, 0, 4 * sizeof(int), e->stream));
   int bmax = 1;
   for (const DenseBlk &d : e->dP_blks) bmax = std::max(bmax, d.b);
-  hipLaunchKernelGGL(k_blk_invert, dim3(std::min(nb, 1024)), dim3(TB), (size_t)bmax * bmax * sizeof(double), e->stream, e->c, e->bd);
+  hipLaunchKernelGGL(k_blk_invert, dim3(std::min(nb, 1024)), dim3(INV_TB), (size_t)bmax * bmax * sizeof(double), e->stream, e->c, e->bd);
   if (e->bd.kc) {
     // capacitance matrix, rows r0 .. r0 + 15 = S (B^-1 S_g')': one block pass on the matrix cores and 16 kc row dots per group,
     // then the diagonal and kc pivot steps; everything on the stream
