@@ -394,7 +394,7 @@ def cpu_baseline_join(proc, cpu_n):
 
 def rowpart_config5(dist, rank, world, dev_id, eps):
     """BASELINE config 5 "1 -> N MI355X": ONE portfolio QP whose rows of A and blocks of P are sharded over the N ranks
-    (osqp_amd/rowpart.py: one n-vector all-reduce per PCG iteration), next to the same QP on one GPU (rank 0).  Only run
+    (include/osqp_amd_rowpart.h: one n-vector all-reduce per PCG iteration, loop in C), next to the same QP on one GPU (rank 0).  Only run
     with N > 1.  Status per DESIGN.md section 7: bound by all-reduce latency; it cannot beat one GPU's block-direct solve
     at this size -- the leg exists so that a multi-GPU node measures that curve instead of leaving it to an estimate."""
     import torch
@@ -404,7 +404,10 @@ def rowpart_config5(dist, rank, world, dev_id, eps):
     pb = portfolio_qp()
     kw = dict(eps_abs=eps, eps_rel=eps, adaptive_rho_interval=100)
     scaled = rowpart.scaled_problem_from_engine(**pb, device=dev_id)
-    rp = rowpart.RowPartitionedOSQP().setup(scaled, rowpart.HipOps, device=dev_id, **kw)
+    # the loop driven from C (osqp_amd_rp_solve, include/osqp_amd_rowpart.h): with the nccl backend its collectives are
+    # ncclAllReduce on the engine's stream, with gloo (rehearsal) the group serves as a callback
+    rp = rowpart.NativeRowPartitionedOSQP(collective="auto").setup(scaled, device=dev_id, **kw)
+    driver = "osqp_amd_rp_solve (C), collective: " + rp.collective
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     r = rp.solve()
@@ -417,7 +420,7 @@ def rowpart_config5(dist, rank, world, dev_id, eps):
         t1 = time.perf_counter(); r1 = s1.solve(); d1 = time.perf_counter() - t1
         out = dict(workload="config5 portfolio n=50000 (400 dense blocks of 125), ONE QP row-partitioned over %d ranks" % world,
                    status=r.info.status, admm_iters=int(r.info.iter), solve_s=round(dt, 4), admm_iters_per_s=round(r.info.iter / dt, 1),
-                   pcg_iters=int(r.info.pcg_iters), collectives=int(r.info.collectives),
+                   pcg_iters=int(r.info.pcg_iters), collectives=int(r.info.collectives), driver=driver,
                    single_gpu=dict(status=r1.info.status, admm_iters=int(r1.info.iter), admm_iters_per_s=round(r1.info.iter / d1, 1)),
                    note="rows of A and blocks of P sharded, n-vectors replicated, one n-vector all-reduce per PCG iteration; the single-GPU figure "
                         "is the block-direct solve (DESIGN.md 2b)")

@@ -4340,3 +4340,6 @@ extern "C" int hipeng_kernel_bytes(hipeng *e, int which, double *bytes) {
   else                 *bytes = 0;
   return 0;
 }
+
+// ---- ONE QP over several GPUs by rows, driven from C (include/osqp_amd_rowpart.h) ----
+#include "rowpart_native.h"

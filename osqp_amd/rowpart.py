@@ -383,3 +383,180 @@ class RowPartitionedOSQP:
                                rho_updates=self.rho_updates, rho_estimate=self._rho_estimate(), pcg_iters=self.pcg_iters,
                                collectives=self.collectives)
         return SimpleNamespace(x=x, y=y, info=info)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The same solve driven from C (include/osqp_amd_rowpart.h, csrc/rowpart_native.h): kernels, collectives and the PCG's
+# stopping decisions are issued by osqp_amd_rp_solve on the shard engine's stream.  Python only shards the matrices,
+# creates the engine and -- for a gloo rehearsal -- lends its process group as the collective.
+# ------------------------------------------------------------------------------------------------------------------
+class _RpSettings(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("rho", "sigma", "alpha", "eps_abs", "eps_rel", "adaptive_rho_tolerance", "pcg_eps_rel")] + \
+               [(k, C.c_int) for k in ("max_iter", "check_termination", "adaptive_rho", "adaptive_rho_interval", "scaled_termination", "pcg_max_iter")]
+
+
+class _RpInfo(C.Structure):
+    _fields_ = [("status", C.c_int), ("iter", C.c_int), ("rho_updates", C.c_int), ("pcg_iters", C.c_longlong), ("collectives", C.c_longlong),
+                ("obj_val", C.c_double), ("pri_res", C.c_double), ("dua_res", C.c_double), ("rho_estimate", C.c_double)]
+
+
+_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p)
+_STATUS = {1: "solved", 2: "solved inaccurate", -2: "maximum iterations reached"}
+
+
+class _DevView:
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = dict(shape=(int(count),), typestr="<f8", data=(int(ptr), False), version=2, strides=None)
+
+
+class NativeRowPartitionedOSQP:
+    """osqp_setup / osqp_solve of ONE row-partitioned QP through the C entry points osqp_amd_rp_*.
+    collective = "rccl": ncclAllReduce of librccl on the engine's stream (the production path, one GPU per rank);
+                 "group": the torch.distributed group as a callback (any backend; gloo stages through the host);
+                 "auto": rccl when the group's backend is nccl, else group."""
+
+    def __init__(self, group=None, collective="auto", world=None):
+        # world=1: no process group and no torch at all (a plain C caller's situation; tools/rccl_world1_probe.py)
+        self.torch = self.dist = None
+        self.group, self.world, self.rank = group, 1, 0
+        if world != 1:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+            if collective == "auto":
+                collective = "rccl" if (dist.is_initialized() and dist.get_backend(group) == "nccl") else "group"
+        self.collective = "group" if collective == "auto" else collective
+        self._rp = None
+
+    def _bind(self, L):
+        L.osqp_amd_rp_create.restype = C.c_void_p
+        L.osqp_amd_rp_create.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_double, C.c_int, C.c_int, C.POINTER(_RpSettings), C.c_int, C.c_int, _ALLREDUCE_FN, C.c_void_p]
+        L.osqp_amd_rp_solve.restype = C.c_int; L.osqp_amd_rp_solve.argtypes = [C.c_void_p, C.POINTER(_RpInfo)]
+        L.osqp_amd_rp_get_solution.restype = C.c_int; L.osqp_amd_rp_get_solution.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.osqp_amd_rp_free.restype = None; L.osqp_amd_rp_free.argtypes = [C.c_void_p]
+        L.osqp_amd_rp_rccl_unique_id.restype = C.c_int; L.osqp_amd_rp_rccl_unique_id.argtypes = [C.c_void_p, C.c_int]
+        L.osqp_amd_rp_use_rccl.restype = C.c_int; L.osqp_amd_rp_use_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.hipeng_sync.restype = C.c_int; L.hipeng_sync.argtypes = [C.c_void_p]
+
+    def _group_allreduce(self, user, buf, count, op, stream):
+        # the callback form of the collective: everything queued on the engine's stream first, then the group's all-reduce on
+        # the wrapped device memory, complete before this returns (osqp_amd_rowpart.h: "a synchronous one")
+        try:
+            t, d = self.torch, self.dist
+            if self._L.hipeng_sync(self._e):
+                return 1
+            v = t.as_tensor(_DevView(buf, count), device=self.dev)
+            rop = d.ReduceOp.MAX if op else d.ReduceOp.SUM
+            if d.get_backend(self.group) == "nccl":
+                d.all_reduce(v, op=rop, group=self.group)
+            else:
+                h = v.cpu(); d.all_reduce(h, op=rop, group=self.group); v.copy_(h)
+            t.cuda.synchronize(self.dev)
+            return 0
+        except Exception as ex:                          # an exception must not unwind through the C frames
+            import sys
+            print("osqp_amd.rowpart: collective failed: %r" % (ex,), file=sys.stderr)
+            return 1
+
+    def setup(self, scaled, device=0, **settings):
+        t, d = self.torch, self.dist
+        st = dict(rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000, check_termination=25,
+                  adaptive_rho=1, adaptive_rho_interval=0, adaptive_rho_tolerance=5.0, scaled_termination=0,
+                  pcg_eps_rel=1e-9, pcg_max_iter=0)
+        for k, v in settings.items():
+            if k not in st:
+                raise ValueError("unsupported setting %r in the row-partitioned variant" % k)
+            st[k] = v
+        n, m = scaled["P"].shape[0], scaled["A"].shape[0]
+        self.n, self.m = n, m
+        self.rows = shard_rows(scaled["A"], self.world)
+        r0, r1 = self.rows[self.rank]
+        self.r0, self.r1 = r0, r1
+        # the rank's shard (P_g, A_g) in an ordinary engine: scaling = 0 on already scaled data
+        import osqp_amd
+        Pg, Ag = shard_triu(scaled["P"], self.world)[self.rank], sparse.csr_matrix(scaled["A"])[r0:r1]
+        old = osqp_amd.engine_options()["device"]
+        osqp_amd.set_engine_options(device=device)
+        try:
+            self.shard = osqp_amd.OSQP().setup(P=Pg, q=np.zeros(n), A=Ag, l=-np.ones(r1 - r0), u=np.ones(r1 - r0), scaling=0, sigma=1.0)
+        finally:
+            osqp_amd.set_engine_options(device=old)
+        self.dev = t.device("cuda", device) if t is not None else None
+        L = self.shard._lib
+        self._bind(L)
+        self._L, self._e = L, self.shard.engine()
+        lg, ug = np.ascontiguousarray(scaled["l"][r0:r1], dtype=np.float64), np.ascontiguousarray(scaled["u"][r0:r1], dtype=np.float64)
+        has_eq = float(np.any(ug - lg < RHO_TOL))
+        if self.world > 1:
+            flag = t.tensor([has_eq], dtype=t.float64, device=self.dev if d.get_backend(self.group) == "nccl" else "cpu")
+            d.all_reduce(flag, op=d.ReduceOp.MAX, group=self.group)
+            has_eq = float(flag.item())
+        kinds = dict(_RpSettings._fields_)
+        s = _RpSettings(**{k: (float(v) if kinds[k] is C.c_double else int(v)) for k, v in st.items()})
+        self._cb = _ALLREDUCE_FN(self._group_allreduce)              # kept alive with the object
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        q, D, E = f64(scaled["q"]), f64(scaled["D"]), f64(scaled["E"][r0:r1])
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None
+        self._rp = L.osqp_amd_rp_create(self._e, ptr(q), ptr(lg), ptr(ug), ptr(D), ptr(E), float(scaled["c"]), int(m), int(has_eq > 0),
+                                        C.byref(s), self.world, self.rank, self._cb, None)
+        if not self._rp:
+            raise RuntimeError("osqp_amd_rp_create failed")
+        if self.collective == "rccl" and self.world > 1:
+            idb = t.zeros(128, dtype=t.uint8)
+            if self.rank == 0:
+                raw = (C.c_char * 128)()
+                if L.osqp_amd_rp_rccl_unique_id(raw, 128) != 128:
+                    raise RuntimeError("osqp_amd_rp_rccl_unique_id failed")
+                idb = t.frombuffer(bytearray(raw.raw), dtype=t.uint8).clone()
+            on = self.dev if d.get_backend(self.group) == "nccl" else "cpu"
+            idb = idb.to(on)
+            d.broadcast(idb, src=0, group=self.group)
+            raw = bytes(idb.cpu().numpy().tobytes())
+            bad = t.tensor([float(L.osqp_amd_rp_use_rccl(self._rp, raw, 128) != 0)], dtype=t.float64, device=on)
+            d.all_reduce(bad, op=d.ReduceOp.MAX, group=self.group)
+            if bad.item() > 0:                         # every rank takes the same decision: the group serves as the collective
+                import sys
+                print("osqp_amd.rowpart: RCCL could not be attached on some rank; the process group is the collective", file=sys.stderr)
+                L.osqp_amd_rp_use_rccl(self._rp, None, 0)
+                self.collective = "group"
+        return self
+
+    def use_rccl_world1(self):
+        """Test hook: the built-in RCCL provider on a one-rank communicator (dlopen, ncclCommInitRank, the stream-ordered call)."""
+        raw = (C.c_char * 128)()
+        if self._L.osqp_amd_rp_rccl_unique_id(raw, 128) != 128:
+            raise RuntimeError("osqp_amd_rp_rccl_unique_id failed")
+        return self._L.osqp_amd_rp_use_rccl(self._rp, raw.raw, 128)
+
+    def solve(self):
+        from types import SimpleNamespace
+        t, d = self.torch, self.dist
+        info = _RpInfo()
+        rc = self._L.osqp_amd_rp_solve(self._rp, C.byref(info))
+        if rc:
+            raise RuntimeError("osqp_amd_rp_solve failed (%d)" % rc)
+        x = np.zeros(self.n); yl = np.zeros(max(self.r1 - self.r0, 1))
+        if self._L.osqp_amd_rp_get_solution(self._rp, x.ctypes.data_as(C.c_void_p), yl.ctypes.data_as(C.c_void_p)):
+            raise RuntimeError("osqp_amd_rp_get_solution failed")
+        yl = yl[:self.r1 - self.r0]
+        if self.world > 1:                                  # the duals are gathered from the row shards (once per solve, off the data path)
+            per = max(b - a for a, b in self.rows)
+            pad = t.zeros(per, dtype=t.float64); pad[:yl.size] = t.from_numpy(yl)
+            if d.get_backend(self.group) == "nccl":
+                pad = pad.to(self.dev)
+            out = t.empty(self.world * per, dtype=t.float64, device=pad.device)
+            d.all_gather_into_tensor(out, pad, group=self.group)
+            out = out.cpu().numpy()
+            y = np.concatenate([out[g * per:g * per + (b - a)] for g, (a, b) in enumerate(self.rows)])
+        else:
+            y = yl
+        ns = SimpleNamespace(status=_STATUS.get(info.status, "unsolved"), iter=info.iter, obj_val=info.obj_val, pri_res=info.pri_res, dua_res=info.dua_res,
+                             rho_updates=info.rho_updates, rho_estimate=info.rho_estimate, pcg_iters=info.pcg_iters, collectives=info.collectives)
+        return SimpleNamespace(x=x, y=y, info=ns)
+
+    def cleanup(self):
+        if self._rp:
+            self._L.osqp_amd_rp_free(self._rp)
+            self._rp = None

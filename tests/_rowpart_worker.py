@@ -1,5 +1,5 @@
 """One rank of the row-partitioned solve (started by tests/test_rowpart.py through osqp_amd.launch.spawn_ranks).
-usage: _rowpart_worker.py <cpu|gpu> <problem> <out.npz>"""
+usage: _rowpart_worker.py <cpu|gpu|native> <problem> <out.npz>   (native: the loop driven from C, osqp_amd_rp_solve; the gloo group as its collective)"""
 import os
 import sys
 
@@ -28,7 +28,10 @@ if mode == "cpu":     # CPU rehearsal of the collective logic: scipy SpMVs, scal
 else:
     scaled = rowpart.scaled_problem_from_engine(**pb)
     ops = rowpart.HipOps
-r = rowpart.RowPartitionedOSQP().setup(scaled, ops, device=0, **kw).solve()
+if mode == "native":
+    r = rowpart.NativeRowPartitionedOSQP(collective="group").setup(scaled, device=0, **kw).solve()
+else:
+    r = rowpart.RowPartitionedOSQP().setup(scaled, ops, device=0, **kw).solve()
 if dist.get_rank() == 0:
     np.savez(out, x=r.x, y=r.y, iter=r.info.iter, status=r.info.status, obj=r.info.obj_val, rho_updates=r.info.rho_updates,
              pcg_iters=r.info.pcg_iters, collectives=r.info.collectives, world=dist.get_world_size())
