@@ -171,6 +171,12 @@ int hipeng_resident_plan(const csc *P, const csc *A, int nwg, long long stats[8]
 /* For the tests: K as the resident kernel holds it, as triplets; returns nnz(K) or a negative code. */
 long long hipeng_resident_dump(hipeng *e, int *row, int *col, double *val, long long cap);
 
+/* Dense-direct solve (engine.hip res_kind 4, csrc/dense_direct.h): test / measurement hook for its blocked inversion.
+ * A: n x n row-major symmetric positive definite host matrix, n a multiple of 128; Ainv: its inverse (explicit, by blocked
+ * Gauss-Jordan on v_mfma_f64_16x16x4_f64); ms[0]: device time of the inversion, ms[1]: of one n x n x n GEMM of the same
+ * kernel.  Returns 0, 1 when a pivot was not positive, or a HIPENG_ERR_* code. */
+int hipeng_dense_invert_selftest(int n, const double *A, double *Ainv, double *ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,283 @@
+// dense_direct.h -- included by engine.hip after the elimination and block forms (it uses Ctx, State, k_blk-style helpers).
+//
+// Dense-direct solve (res_kind 4): problems whose reduced matrix K = P + sigma I + A' rho~ A is SMALL AND DENSE -- BASELINE
+// config 3, the Lasso QP: 5 000 feature variables tied together by 10 000 data rows of 750 entries.  There the PCG streams the
+// 90 MB of A twice per iteration, 22 times per ADMM iteration; the matrix it inverts piecemeal is only 5 000 x 5 000.
+// So K is formed as a dense matrix, inverted explicitly on the matrix cores whenever rho / sigma / the matrices change, and one
+// linear solve is ONE pass over the 210 MB of K^-1 (as the block-direct solve of the portfolio family, with one block).
+//
+//   unknowns of the engine's reduced system (variables not eliminated by k_elim_*):
+//     B2  "sparse" variables: not in any dense row of A, no off-diagonal entry in P, at most DD_NBR neighbours, pairwise not
+//         adjacent (Lasso: the 5 000 bound variables t_j, which meet x_j only).  K_B2,B2 is diagonal: they leave the system by an
+//         exact sparse Schur complement (private to this solver: r_a -= K_aB D^-1 r_B before, v_B = D^-1 (r_B - K_Ba v_a) after);
+//     a   everything else (n_a <= DD_MAX): the dense Schur complement  S = K_aa - K_aB D^-1 K_Ba.
+//   formation (dd_refresh):  S = R' diag(w) R  over the dense rows of A (R: n_d x n_a, built from the CSR rows; one TN GEMM on
+//     v_mfma_f64_16x16x4_f64) + the short rows, P and sigma scattered with atomics + the Schur terms; then the explicit inverse by
+//     blocked Gauss-Jordan (128-wide pivot blocks inverted in LDS, every other flop in the same GEMM kernel).
+//   solve (launch_dense_direct): k_dd_reduce -> k_dd_gemv (v_a = S^-1 r_a, HBM-bound) -> k_dd_finish, applied to the residual
+//     r0 = b - K x~0 that k_pcg_init forms (refinement form, as the block-direct solve).
+#define DD_NB 128
+#define DD_MAX 8192
+#define DD_NBR 8
+#define DD_DENSE_ROW 32
+
+struct DdCtx {
+  int na, nap, nb2, nd;
+  const int *vidx;          // [n] variable -> dense index (>= 0), -(b + 2) for B2 variable b, -1: eliminated by the engine
+  const int *alist, *blist; // [na], [nb2] variable of a dense index / of a B2 index
+  const int *bnbr;          // [nb2][DD_NBR] dense indices of a B2 variable's neighbours (-1: none)
+  double *bval, *bdiag;     // [nb2][DD_NBR] K(b, neighbour), [nb2] K(b, b)
+  double *S;                // [nap][nap] Schur complement, then its inverse
+  double *R, *dw;           // [nd][nap] dense rows of A over the dense unknowns; [nd] their weights rho~
+  const int *drow;          // [nd] row of A
+  const char *isdense;      // [m] 1: the row is in R
+  double *rr, *vv;          // [nap] reduced residual, solution
+  double *D, *Bp, *T;       // inversion: pivot block inverse [128][128], packed row panel [128][nap], transposed column panel [128][nap]
+  int *flag;                // [0] a pivot was not positive
+};
+
+// C = beta C + alpha T' diag(w) B on v_mfma_f64_16x16x4_f64.  T: [K][ldt] (so the A operand A[i][k] = T[k][i] is 4 rows x 16
+// contiguous doubles per wave load), B: [K][ldb], C: [M][ldc].  Workgroup = 128 x 128 of C, wavefront = 64 x 64 = 4 x 4 tiles.
+// Tiles whose rows lie in [sr0, sr1) or columns in [sc0, sc1) are left alone (the pivot block row / column of a Gauss-Jordan step).
+__global__ void __launch_bounds__(TB) k_dd_gemm_tn(double *C, int ldc, const double *T, int ldt, const double *B, int ldb, const double *w,
+                                                   int M, int N, int K, double alpha, double beta, int sr0, int sr1, int sc0, int sc1) {
+  const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;
+  if ((row0 >= sr0 && row0 < sr1) || (col0 >= sc0 && col0 < sc1)) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  const int wr = row0 + (wv >> 1) * 64, wc = col0 + (wv & 1) * 64;
+  mfma_d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  // K in chunks of 16 (four MFMA steps): the 32 operand loads of the NEXT chunk are issued before the 64 MFMAs of this one
+  // (one wavefront per SIMD at 128 accumulator registers: nothing else hides the L2 round trip)
+  double a[4][4], b[4][4], an[4][4], bn[4][4];
+  auto load = [&](int k0, double (&aa)[4][4], double (&bb)[4][4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int kk = k0 + 4 * s + lk;
+      const bool kv = kk < K;
+      const double wk = (w && kv) ? w[kk] : 1.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = wr + 16 * t + li, c = wc + 16 * t + li;
+        aa[s][t] = (kv && r < M) ? T[(size_t)kk * ldt + r] : 0.0;
+        bb[s][t] = (kv && c < N) ? B[(size_t)kk * ldb + c] * wk : 0.0;
+      }
+    }
+  };
+  load(0, a, b);
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    if (k0 + 16 < K) load(k0 + 16, an, bn);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { a[s][t] = an[s][t]; b[s][t] = bn[s][t]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {              // D[row = lk + 4 r][col = li] of the tile
+        const int row = wr + 16 * i + lk + 4 * r, col = wc + 16 * j + li;
+        if (row < M && col < N) {
+          double *p = C + (size_t)row * ldc + col;
+          *p = beta == 0.0 ? alpha * acc[i][j][r] : beta * *p + alpha * acc[i][j][r];
+        }
+      }
+}
+
+// D = (pivot block kb of A)^-1: Gauss-Jordan in LDS without pivoting (the Schur complements of a positive definite matrix are
+// positive definite; a non-positive pivot raises the flag)
+__global__ void __launch_bounds__(INV_TB) k_dd_pivot(const double *A, int lda, int kb, double *D, int *flag) {
+  extern __shared__ __attribute__((aligned(16))) double bl[];       // 128 x 128
+  __shared__ double colp[DD_NB], rowp[DD_NB];
+  constexpr int RS = INV_TB / DD_NB, RU = DD_NB / RS;
+  const int t = threadIdx.x, j = t & (DD_NB - 1), i0 = t / DD_NB;
+  const double *src = A + (size_t)kb * DD_NB * lda + (size_t)kb * DD_NB;
+  for (int i = i0; i < DD_NB; i += RS) bl[i * DD_NB + j] = src[(size_t)i * lda + j];
+  __syncthreads();
+  for (int p = 0; p < DD_NB; ++p) {
+    if (t < DD_NB) { colp[t] = bl[t * DD_NB + p]; rowp[t] = bl[p * DD_NB + t]; }
+    __syncthreads();
+    const double piv = rowp[p];
+    if (!(piv > 0.0) && t == 0) atomicOr(flag, 1);
+    const double inv = 1.0 / piv, rj = rowp[j] * inv;
+    double cur[RU], cp[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) { const int i = i0 + RS * u; cur[u] = bl[i * DD_NB + j]; cp[u] = colp[i]; }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int i = i0 + RS * u;
+      double v;
+      if (i == p) v = (j == p) ? inv : rj;
+      else if (j == p) v = -cp[u] * inv;
+      else v = cur[u] - cp[u] * rj;
+      bl[i * DD_NB + j] = v;
+    }
+    __syncthreads();
+  }
+  for (int i = i0; i < DD_NB; i += RS) D[i * DD_NB + j] = bl[i * DD_NB + j];
+}
+// Bp = row panel kb of A (packed [128][n]); T = column panel kb transposed ([128][n]): 64 rows of A per workgroup through LDS
+__global__ void __launch_bounds__(TB) k_dd_panels(const double *A, int lda, int n, int kb, double *Bp, double *T) {
+  __shared__ double tile[64][DD_NB + 1];
+  const int i0 = blockIdx.x * 64;
+  for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) {
+    const int i = q / DD_NB, r = q % DD_NB;
+    tile[i][r] = i0 + i < n ? A[(size_t)(i0 + i) * lda + (size_t)kb * DD_NB + r] : 0.0;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) {
+    const int r = q / 64, i = q % 64;
+    if (i0 + i < n) T[(size_t)r * n + i0 + i] = tile[i][r];
+  }
+  // this workgroup's 64 columns of the row panel
+  for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) {
+    const int r = q / 64, jx = q % 64;
+    if (i0 + jx < n) Bp[(size_t)r * n + i0 + jx] = A[((size_t)kb * DD_NB + r) * lda + i0 + jx];
+  }
+}
+__global__ void __launch_bounds__(TB) k_dd_setblock(double *A, int lda, int kb, const double *D) {
+  for (int q = blockIdx.x * TB + threadIdx.x; q < DD_NB * DD_NB; q += gridDim.x * TB)
+    A[((size_t)kb * DD_NB + q / DD_NB) * lda + (size_t)kb * DD_NB + q % DD_NB] = D[q];
+}
+
+// A (n x n, n a multiple of 128, symmetric positive definite) <- A^-1 in place on `stream`.  Per pivot block: invert it (D), pack
+// the row panel and the transposed column panel, then  row panel = D Bp;  everything else -= T' (row panel);  column panel = -T' D.
+static int dd_invert(hipStream_t stream, double *A, int n, double *D, double *Bp, double *T, int *flag) {
+  static bool lds_set = false;
+  if (!lds_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dd_pivot), hipFuncAttributeMaxDynamicSharedMemorySize, DD_NB * DD_NB * (int)sizeof(double)) != hipSuccess) return HIPENG_ERR_HIP;
+    lds_set = true;
+  }
+  const int nb = n / DD_NB;
+  const dim3 gfull(nb, nb), grow(nb, 1), gcol(1, nb);
+  for (int kb = 0; kb < nb; kb++) {
+    const int p0 = kb * DD_NB, p1 = p0 + DD_NB;
+    hipLaunchKernelGGL(k_dd_pivot, dim3(1), dim3(INV_TB), DD_NB * DD_NB * sizeof(double), stream, (const double *)A, n, kb, D, flag);
+    hipLaunchKernelGGL(k_dd_panels, dim3((n + 63) / 64), dim3(TB), 0, stream, (const double *)A, n, n, kb, Bp, T);
+    hipLaunchKernelGGL(k_dd_gemm_tn, grow, dim3(TB), 0, stream, A + (size_t)p0 * n, n, (const double *)D, DD_NB, (const double *)Bp, n, (const double *)nullptr,
+                       DD_NB, n, DD_NB, 1.0, 0.0, -1, -1, p0, p1);
+    hipLaunchKernelGGL(k_dd_gemm_tn, gfull, dim3(TB), 0, stream, A, n, (const double *)T, n, (const double *)(A + (size_t)p0 * n), n, (const double *)nullptr,
+                       n, n, DD_NB, -1.0, 1.0, p0, p1, p0, p1);
+    hipLaunchKernelGGL(k_dd_gemm_tn, gcol, dim3(TB), 0, stream, A + p0, n, (const double *)T, n, (const double *)D, DD_NB, (const double *)nullptr,
+                       n, DD_NB, DD_NB, -1.0, 0.0, p0, p1, -1, -1);
+    hipLaunchKernelGGL(k_dd_setblock, dim3(16), dim3(TB), 0, stream, A, n, kb, (const double *)D);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- formation ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TB) k_dd_fill_R(Ctx c, DdCtx dd) {
+  const int d = blockIdx.x, i = dd.drow[d];
+  double *row = dd.R + (size_t)d * dd.nap;
+  for (int k = c.A.rowptr[i] + (int)threadIdx.x; k < c.A.rowptr[i + 1]; k += TB) {
+    const int a = dd.vidx[c.A.col[k]];
+    if (a >= 0) row[a] = c.A.val[k];
+  }
+  if (threadIdx.x == 0) dd.dw[d] = c.rhoe[i];
+}
+__device__ __forceinline__ void dd_add_pair(const DdCtx &dd, int cp, int cq, double v, bool same) {
+  if (cp >= 0) { if (cq >= 0) atomicAdd(dd.S + (size_t)cp * dd.nap + cq, v); return; }
+  if (cp == -1) return;
+  const int b = -cp - 2;
+  if (same) { atomicAdd(dd.bdiag + b, v); return; }
+  if (cq < 0) return;
+  for (int s = 0; s < DD_NBR; ++s) if (dd.bnbr[b * DD_NBR + s] == cq) { atomicAdd(dd.bval + b * DD_NBR + s, v); return; }
+}
+// the short rows of A (one thread each: every pair of its entries), then P and sigma (one thread per variable)
+__global__ void __launch_bounds__(TB) k_dd_scatter(Ctx c, DdCtx dd) {
+  const double sigma = c.prm->sigma;
+  for (int i = blockIdx.x * TB + threadIdx.x; i < c.m; i += gridDim.x * TB) {
+    if (dd.isdense[i]) continue;
+    const double w = c.rhoe[i];
+    for (int p = c.A.rowptr[i]; p < c.A.rowptr[i + 1]; ++p) {
+      const int cp = dd.vidx[c.A.col[p]];
+      if (cp == -1) continue;
+      const double ap = w * c.A.val[p];
+      for (int q = c.A.rowptr[i]; q < c.A.rowptr[i + 1]; ++q) dd_add_pair(dd, cp, dd.vidx[c.A.col[q]], ap * c.A.val[q], p == q);
+    }
+  }
+  for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
+    const int cj = dd.vidx[j];
+    if (cj == -1) continue;
+    dd_add_pair(dd, cj, cj, sigma, true);
+    for (int k = c.M.rowptr[j]; k < c.M.split[j]; ++k) dd_add_pair(dd, cj, dd.vidx[c.M.col[k]], c.M.val[k], c.M.col[k] == j);
+  }
+}
+// S -= K_aB D^-1 K_Ba (one thread per B2 variable); the padding rows get a unit diagonal
+__global__ void __launch_bounds__(TB) k_dd_schur(DdCtx dd) {
+  for (int b = blockIdx.x * TB + threadIdx.x; b < dd.nb2; b += gridDim.x * TB) {
+    const double di = 1.0 / dd.bdiag[b];
+    if (!(dd.bdiag[b] > 0.0)) atomicOr(dd.flag, 1);
+    for (int s = 0; s < DD_NBR; ++s) {
+      const int as = dd.bnbr[b * DD_NBR + s];
+      if (as < 0) continue;
+      const double vs = dd.bval[b * DD_NBR + s] * di;
+      for (int t = 0; t < DD_NBR; ++t) { const int at = dd.bnbr[b * DD_NBR + t]; if (at >= 0) atomicAdd(dd.S + (size_t)as * dd.nap + at, -vs * dd.bval[b * DD_NBR + t]); }
+    }
+  }
+  for (int a = dd.na + blockIdx.x * TB + threadIdx.x; a < dd.nap; a += gridDim.x * TB) dd.S[(size_t)a * dd.nap + a] = 1.0;
+}
+
+// ---- solve ----------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TB) k_dd_gather(Ctx c, DdCtx dd) {
+  { const State *st = c.st; if (st->stalled || !st->run) return; }
+  for (int a = blockIdx.x * TB + threadIdx.x; a < dd.nap; a += gridDim.x * TB) dd.rr[a] = a < dd.na ? c.init_r[dd.alist[a]] : 0.0;
+}
+__global__ void __launch_bounds__(TB) k_dd_reduce(Ctx c, DdCtx dd) {
+  { const State *st = c.st; if (st->stalled || !st->run) return; }
+  for (int b = blockIdx.x * TB + threadIdx.x; b < dd.nb2; b += gridDim.x * TB) {
+    const double rb = c.init_r[dd.blist[b]] / dd.bdiag[b];
+    for (int s = 0; s < DD_NBR; ++s) { const int a = dd.bnbr[b * DD_NBR + s]; if (a >= 0) atomicAdd(dd.rr + a, -dd.bval[b * DD_NBR + s] * rb); }
+  }
+}
+// vv = S^-1 rr: one wavefront per row of the (symmetric) inverse, the vector in LDS; 210 MB at n_a = 5 000 -- the pass that bounds a solve
+__global__ void __launch_bounds__(TB) k_dd_gemv(Ctx c, DdCtx dd) {
+  { const State *st = c.st; if (st->stalled || !st->run) return; }
+  extern __shared__ __attribute__((aligned(16))) double xs[];
+  const int nap = dd.nap;
+  for (int q = threadIdx.x; q < nap; q += TB) xs[q] = dd.rr[q];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wv; row < nap; row += gridDim.x * 4) {
+    const double2 *src = reinterpret_cast<const double2 *>(dd.S + (size_t)row * nap);
+    const double2 *x2 = reinterpret_cast<const double2 *>(xs);
+    double s0 = 0.0, s1 = 0.0;
+    for (int q = lane; q < nap / 2; q += 64) { const double2 v = src[q], x = x2[q]; s0 += v.x * x.x; s1 += v.y * x.y; }
+    const double s = wave_sum(s0 + s1);
+    if (lane == 0) dd.vv[row] = s;
+  }
+}
+// x~ = x~0 + v on the unknowns of the reduced system (the engine's eliminated variables are k_admm_finalize's); solve complete
+__global__ void __launch_bounds__(TB) k_dd_finish(Ctx c, DdCtx dd) {
+  State *st = c.st;
+  if (st->stalled || !st->run) return;
+  for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
+    const int cj = dd.vidx[j];
+    if (cj == -1) continue;
+    double v;
+    if (cj >= 0) v = dd.vv[cj];
+    else {
+      const int b = -cj - 2;
+      double s = c.init_r[j];
+      for (int q = 0; q < DD_NBR; ++q) { const int a = dd.bnbr[b * DD_NBR + q]; if (a >= 0) s -= dd.bval[b * DD_NBR + q] * dd.vv[a]; }
+      v = s / dd.bdiag[b];
+    }
+    c.va[j] = c.vx[j] + v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->iters[0] = 1; st->iters[1] = 0; st->done = 1;
+    if (*dd.flag) st->neg_curv = 1;
+  }
+}

@@ -1,0 +1,134 @@
+// dense_direct_host.h -- host side of the dense-direct solve (kernels: dense_direct.h); included by engine.hip after build_elim.
+static int build_dense_direct(hipeng *e, const csc *P, const csc *A) {
+  int want = 1;
+  if (const char *x = getenv("OSQP_AMD_DENSE_DIRECT")) want = atoi(x);
+  const int n = e->n, m = e->m;
+  if (!want || e->res_on || e->res_kind != 0 || n == 0 || m == 0) return 0;
+  auto gone = [&](int j) { return !e->erow.empty() && e->erow[j] >= 0; };
+  // rows of A over the unknowns of the reduced system: dense (>= DD_DENSE_ROW entries: a row of R) or short (scattered)
+  std::vector<char> isdense(m, 0), indense(n, 0), coupledP(n, 0);
+  std::vector<int> drow;
+  for (int i = 0; i < m; i++) {
+    int len = 0;
+    for (int k = e->A.rowptr[i]; k < e->A.rowptr[i + 1]; k++) len += !gone(e->A.col[k]);
+    if (len >= DD_DENSE_ROW) { isdense[i] = 1; drow.push_back(i); for (int k = e->A.rowptr[i]; k < e->A.rowptr[i + 1]; k++) indense[e->A.col[k]] = 1; }
+  }
+  for (int j = 0; j < n; j++)
+    for (long long k = P->p[j]; k < P->p[j + 1]; k++) if (P->i[k] != j) { coupledP[j] = 1; coupledP[(int)P->i[k]] = 1; }
+  // B2: a greedy independent set of sparse variables (ascending index; a chosen variable blocks its neighbours)
+  std::vector<int> vidx(n, -1), alist, blist, bnbr_var;
+  std::vector<char> blocked(n, 0), chosen(n, 0);
+  std::vector<int> nb;
+  for (int j = 0; j < n; j++) {
+    if (gone(j) || indense[j] || coupledP[j] || blocked[j]) continue;
+    nb.clear();
+    bool ok = true;
+    for (long long k = A->p[j]; k < A->p[j + 1] && ok; k++) {
+      const int i = (int)A->i[k];
+      for (int q = e->A.rowptr[i]; q < e->A.rowptr[i + 1]; q++) {
+        const int v = e->A.col[q];
+        if (v == j || gone(v)) continue;
+        if (chosen[v]) { ok = false; break; }
+        if (std::find(nb.begin(), nb.end(), v) == nb.end()) { nb.push_back(v); if ((int)nb.size() > DD_NBR) { ok = false; break; } }
+      }
+    }
+    if (!ok) continue;
+    chosen[j] = 1;
+    for (int v : nb) blocked[v] = 1;
+    blist.push_back(j);
+    for (int s = 0; s < DD_NBR; s++) bnbr_var.push_back(s < (int)nb.size() ? nb[s] : -1);
+  }
+  for (int j = 0; j < n; j++) if (!gone(j) && !chosen[j]) { vidx[j] = (int)alist.size(); alist.push_back(j); }
+  for (size_t b = 0; b < blist.size(); b++) vidx[blist[b]] = -((int)b + 2);
+  const int na = (int)alist.size(), nb2 = (int)blist.size(), nd = (int)drow.size();
+  if (na == 0 || na > DD_MAX) return 0;
+  const int nap = (na + DD_NB - 1) / DD_NB * DD_NB;
+  // does it pay?  a PCG solve streams A twice and P once per iteration, rarely fewer than eight of them; this one streams the
+  // inverse once (and the refresh costs a few such solves)
+  const double nnzA = (double)e->A.val.size(), nnzP = 2.0 * (double)e->P_toM_up.size();
+  const double bytes_pcg = 8.0 * (2.0 * nnzA + nnzP) * 12.0, bytes_dd = 3.0 * 8.0 * (double)nap * nap;
+  bool pays = bytes_pcg > bytes_dd && (double)nd * nap * 8.0 < 6e9;
+  if (const char *x = getenv("OSQP_AMD_DENSE_DIRECT")) if (atoi(x) == 2) pays = (double)nd * nap * 8.0 < 6e9;      // 2: whenever it fits (tests)
+  if (!pays) return 0;
+  std::vector<int> bnbr(bnbr_var.size());
+  for (size_t q = 0; q < bnbr_var.size(); q++) bnbr[q] = bnbr_var[q] < 0 ? -1 : vidx[bnbr_var[q]];
+  DdCtx dd{};
+  dd.na = na; dd.nap = nap; dd.nb2 = nb2; dd.nd = nd;
+  int *d_vidx = nullptr, *d_alist = nullptr, *d_blist = nullptr, *d_bnbr = nullptr, *d_drow = nullptr; char *d_isdense = nullptr;
+  if (dev_alloc(e, &d_vidx, (size_t)n) || dev_alloc(e, &d_alist, (size_t)na) || dev_alloc(e, &d_blist, (size_t)nb2) || dev_alloc(e, &d_bnbr, bnbr.size()) ||
+      dev_alloc(e, &d_drow, (size_t)nd) || dev_alloc(e, &d_isdense, (size_t)m) || dev_alloc(e, &dd.bval, bnbr.size()) || dev_alloc(e, &dd.bdiag, (size_t)nb2) ||
+      dev_alloc(e, &dd.S, (size_t)nap * nap) || dev_alloc(e, &dd.R, (size_t)nd * nap) || dev_alloc(e, &dd.dw, (size_t)nd) || dev_alloc(e, &dd.rr, (size_t)nap) ||
+      dev_alloc(e, &dd.vv, (size_t)nap) || dev_alloc(e, &dd.D, (size_t)DD_NB * DD_NB) || dev_alloc(e, &dd.Bp, (size_t)DD_NB * nap) || dev_alloc(e, &dd.T, (size_t)DD_NB * nap) ||
+      dev_alloc(e, &dd.flag, (size_t)4)) return HIPENG_ERR_HIP;
+#define DDUP(dst, src) if (!(src).empty()) HIPCHK(hipMemcpyAsync(dst, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, e->stream))
+  DDUP(d_vidx, vidx); DDUP(d_alist, alist); DDUP(d_blist, blist); DDUP(d_bnbr, bnbr); DDUP(d_drow, drow); DDUP(d_isdense, isdense);
+#undef DDUP
+  HIPCHK(hipStreamSynchronize(e->stream));        // (the sources are locals)
+  dd.vidx = d_vidx; dd.alist = d_alist; dd.blist = d_blist; dd.bnbr = d_bnbr; dd.drow = d_drow; dd.isdense = d_isdense;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dd_gemv), hipFuncAttributeMaxDynamicSharedMemorySize, nap * (int)sizeof(double)) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  e->dd = dd;
+  e->c.init_r = e->c.r; e->c.init_stride = 1;
+  e->res_kind = 4; e->res_on = e->res_use = true;
+  if (e->trace) fprintf(stderr, "[osqp_amd] dense-direct solve: %d dense unknowns (%d x %d inverse, %.0f MB), %d sparse unknowns by Schur complement, %d dense rows of A\n",
+                        na, nap, nap, 8e-6 * nap * nap, nb2, nd);
+  return 0;
+}
+
+// New rho, sigma or matrix values: form the Schur complement again and invert it.
+static int dd_refresh(hipeng *e) {
+  const DdCtx &dd = e->dd;
+  const int nap = dd.nap;
+  HIPCHK(hipMemsetAsync(dd.flag, 0, 4 * sizeof(int), e->stream));
+  if (dd.nd) HIPCHK(hipMemsetAsync(dd.R, 0, (size_t)dd.nd * nap * sizeof(double), e->stream));
+  else HIPCHK(hipMemsetAsync(dd.S, 0, (size_t)nap * nap * sizeof(double), e->stream));
+  if (dd.nb2) {
+    HIPCHK(hipMemsetAsync(dd.bval, 0, (size_t)dd.nb2 * DD_NBR * sizeof(double), e->stream));
+    HIPCHK(hipMemsetAsync(dd.bdiag, 0, (size_t)dd.nb2 * sizeof(double), e->stream));
+  }
+  if (dd.nd) {
+    hipLaunchKernelGGL(k_dd_fill_R, dim3(dd.nd), dim3(TB), 0, e->stream, e->c, dd);
+    hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nap / 128, nap / 128), dim3(TB), 0, e->stream, dd.S, nap, (const double *)dd.R, nap, (const double *)dd.R, nap, (const double *)dd.dw,
+                       nap, nap, dd.nd, 1.0, 0.0, -1, -1, -1, -1);
+  }
+  hipLaunchKernelGGL(k_dd_scatter, dim3(elem_grid(std::max(e->n, e->m))), dim3(TB), 0, e->stream, e->c, dd);
+  hipLaunchKernelGGL(k_dd_schur, dim3(elem_grid(std::max(1, std::max(dd.nb2, nap)))), dim3(TB), 0, e->stream, dd);
+  if (int rc = dd_invert(e->stream, dd.S, nap, dd.D, dd.Bp, dd.T, dd.flag)) return rc;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static void launch_dense_direct(hipeng *e) {
+  const DdCtx &dd = e->dd;
+  hipLaunchKernelGGL(k_dd_gather, dim3(elem_grid(dd.nap)), dim3(TB), 0, e->stream, e->c, dd);
+  if (dd.nb2) hipLaunchKernelGGL(k_dd_reduce, dim3(elem_grid(dd.nb2)), dim3(TB), 0, e->stream, e->c, dd);
+  hipLaunchKernelGGL(k_dd_gemv, dim3(std::min(1024, dd.nap / 4)), dim3(TB), (size_t)dd.nap * sizeof(double), e->stream, e->c, dd);
+  hipLaunchKernelGGL(k_dd_finish, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c, dd);
+}
+
+// Test / measurement hook: the blocked inversion alone.  A: n x n row-major symmetric positive definite on the host (n a multiple
+// of 128); Ainv receives the inverse, ms[0] the time of the inversion on the device, ms[1] that of one n x n x n TN GEMM
+// (C = A' A on the matrix cores: the kernel's rate).  Returns 0, or 1 when a pivot was not positive.
+extern "C" int hipeng_dense_invert_selftest(int n, const double *A, double *Ainv, double *ms) {
+  if (n <= 0 || n % DD_NB || !A || !Ainv) return HIPENG_ERR_ARG;
+  double *dA = nullptr, *dC = nullptr, *D = nullptr, *Bp = nullptr, *T = nullptr; int *flag = nullptr;
+  const size_t nn = (size_t)n * n;
+  HIPCHK(hipMalloc(&dA, nn * 8)); HIPCHK(hipMalloc(&dC, nn * 8)); HIPCHK(hipMalloc(&D, DD_NB * DD_NB * 8)); HIPCHK(hipMalloc(&Bp, (size_t)DD_NB * n * 8));
+  HIPCHK(hipMalloc(&T, (size_t)DD_NB * n * 8)); HIPCHK(hipMalloc(&flag, 16));
+  HIPCHK(hipMemcpy(dA, A, nn * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemset(flag, 0, 16));
+  hipEvent_t e0, e1, e2; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+  HIPCHK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k_dd_gemm_tn, dim3(n / 128, n / 128), dim3(TB), 0, 0, dC, n, (const double *)dA, n, (const double *)dA, n, (const double *)nullptr, n, n, n, 1.0, 0.0, -1, -1, -1, -1);
+  HIPCHK(hipEventRecord(e1, 0));
+  if (int rc = dd_invert(0, dA, n, D, Bp, T, flag)) return rc;
+  HIPCHK(hipEventRecord(e2, 0)); HIPCHK(hipEventSynchronize(e2));
+  float t0 = 0, t1 = 0; HIPCHK(hipEventElapsedTime(&t0, e0, e1)); HIPCHK(hipEventElapsedTime(&t1, e1, e2));
+  if (ms) { ms[0] = t1; ms[1] = t0; }
+  int hf = 0;
+  HIPCHK(hipMemcpy(Ainv, dA, nn * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hf, flag, 4, hipMemcpyDeviceToHost));
+  (void)hipFree(dA); (void)hipFree(dC); (void)hipFree(D); (void)hipFree(Bp); (void)hipFree(T); (void)hipFree(flag);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  return hf ? 1 : 0;
+}

@@ -2142,6 +2142,8 @@ __global__ void __launch_bounds__(TB) k_cap_step(BdCtx bd, const double *src, do
   dst[e] = v;
 }
 
+#include "dense_direct.h"
+
 // ---------------------------------------------------------------------------
 // Elimination of slack-like variables from the linear system (launch-per-step kernels and the resident PCG).
 //
@@ -2581,8 +2583,11 @@ struct hipeng {
   long long res_slow_hist[4] = {0, 0, 0, 0}; unsigned res_slow_xcc = 0; int res_slow_last[4] = {0, 0, 0, 0};
   ResCtx rc{};
   BrCtx bc{};                // block-resident form (res_kind 2)
-  int res_kind = 0;          // 0: launch-per-step only, 1: k_pcg_resident, 2: k_pcg_blockres, 3: block-direct solve (k_blk_apply / k_blk_finish)
+  int res_kind = 0;          // 0: launch-per-step only, 1: k_pcg_resident, 2: k_pcg_blockres, 3: block-direct solve (k_blk_apply / k_blk_finish), 4: dense-direct solve (dense_direct.h)
   BdCtx bd{};                // block-direct form (res_kind 3)
+  DdCtx dd{};                // dense-direct form (res_kind 4)
+  bool elim_rhs_dirty = false;   // q, the scaling, the matrices or the iterates changed since the m-part of the right-hand side was formed: with
+                             // eliminated variables it carries their q_y and coefficients (elim_vb), so hipeng_run_admm forms it again first
   std::vector<double> h_rho; // host copy of rho (the capacitance matrix of the block-direct form needs the huge rows' entries)
   std::vector<int> erow, ecol, epos;   // host images of Ctx::erow / ecol / epos (empty: no variable is eliminated)
   size_t res_lds = 0;
@@ -2859,7 +2864,9 @@ template <int E> static int res_set_lds(size_t lds) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pcg_resident<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return 0;
 }
+static void launch_dense_direct(hipeng *e);
 static void launch_resident(hipeng *e) {
+  if (e->res_kind == 4) { launch_dense_direct(e); return; }
   if (e->res_kind == 3) {
     const int gb = std::max(1, std::min(1024, e->c.dP.nblk));
     hipLaunchKernelGGL(k_blk_apply, dim3(gb), dim3(TB), 0, e->stream, e->c, e->bd, (const double *)e->c.init_r, e->bd.t, 1);
@@ -3371,11 +3378,14 @@ static int elem_grid(int cnt) {
 }
 
 // Everything derived from (P, A, rho, sigma): the Jacobi preconditioner.
+static int dd_refresh(hipeng *e);
 static void refresh_operator(hipeng *e) {
+  e->elim_rhs_dirty = true;
   if (e->c.nelim) hipLaunchKernelGGL(k_elim_refresh, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c);
   hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
   if (e->res_kind == 1) hipLaunchKernelGGL(k_form_K, dim3(std::min(2048, (e->n + 3) / 4)), dim3(TB), 0, e->stream, e->c, e->rc);
   if (e->res_kind == 3 && blk_refresh(e)) fprintf(stderr, "osqp_amd: the block-direct solve could not be refreshed\n");
+  if (e->res_kind == 4 && dd_refresh(e)) fprintf(stderr, "osqp_amd: the dense-direct solve could not be refreshed\n");
 }
 
 // The PCG start vector history is void (cold/warm start from the host, new rho, new matrices):
@@ -3435,6 +3445,8 @@ static int build_elim(hipeng *e, const csc *P, const csc *A) {
   if (e->trace) fprintf(stderr, "[osqp_amd] %d of %d variables eliminated from the linear system (one row of A each, no coupling in P)\n", cnt, n);
   return 0;
 }
+
+#include "dense_direct_host.h"
 
 extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_float *q,
                              const c_float *l, const c_float *u, const c_float *rho_vec,
@@ -3551,6 +3563,7 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   if (!e->res_on) if (int rc = build_blockres(e)) return rc;
   if (!e->res_on) { if (int rc = build_resident(e)) return rc; if (e->res_on) e->res_kind = 1; }
   if (int rc = build_elim(e, P, A)) return rc;
+  if (int rc = build_dense_direct(e, P, A)) return rc;
   if (rho_vec) { int rc = hipeng_upload_rho(e, rho_vec); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
@@ -3657,6 +3670,7 @@ extern "C" int hipeng_ruiz_scale(hipeng *e, c_int passes, c_float *D, c_float *E
   if (upload_vec(e, c.pdiag, e->pdiag.data(), n)) return HIPENG_ERR_HIP;
   e->prm.has_scaling = passes > 0 ? 1 : 0; e->prm.cinv = 1.0 / cc;
   if (push_params(e)) return HIPENG_ERR_HIP;
+  e->elim_rhs_dirty = true;
   return 0;
 }
 
@@ -3665,6 +3679,7 @@ extern "C" int hipeng_upload_q(hipeng *e, const c_float *q) {
   HIPCHK(hipSetDevice(e->device));
   if (upload_vec(e, e->c.q, q, e->n)) return HIPENG_ERR_HIP;
   HIPCHK(hipStreamSynchronize(e->stream));
+  e->elim_rhs_dirty = true;
   return 0;
 }
 
@@ -3754,6 +3769,7 @@ extern "C" int hipeng_cold_start(hipeng *e) {
   if (e->c.nelim) HIPCHK(hipMemsetAsync(e->c.xte, 0, (size_t)e->m * sizeof(double), e->stream));
   e->calibrated = false; e->spec_lo = 0;   // the first solve from zero needs far more PCG iterations than the steady state
   e->start_dirty = true;
+  e->elim_rhs_dirty = true;                // (vb = rho z - y = 0 is NOT the whole m-part when a row carries an eliminated variable: -rho a (-q_y) / D_y)
   return 0;
 }
 
@@ -3945,6 +3961,10 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
   // admm_done only moves inside this function: the host keeps its own copy, so a call starts
   // without a device round trip.  The device stops starting iterations at admm_target.
   if (count == 0) return 0;
+  if (e->elim_rhs_dirty) {
+    if (e->c.nelim && e->m > 0) hipLaunchKernelGGL(k_refresh_m, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c, 0);
+    e->elim_rhs_dirty = false;
+  }
   // A launch that gave up (a wait timed out) took the rest of that call to the launch-per-step kernels.  Apart from a GPU
   // that is shared for good, there is a rare transient (about one exchange in 1e5 on small, fast problems: a workgroup's
   // flag or granule stays invisible to some CUs): the next call tries resident launches again, three strikes end that.
@@ -3970,7 +3990,7 @@ extern "C" int hipeng_run_admm(hipeng *e, c_int count) {
     // different engines of this process on one device take turns.  (Across processes there is no such lock: a
     // launch that finds CUs taken times out and the engine falls back, see k_pcg_resident.)
     CuLease lease;
-    if (resident && e->res_kind != 3) lease.take(e->device, e->res_cus, e->res_kind == 2 ? e->bc.nwg : e->rc.nwg);
+    if (resident && e->res_kind < 3) lease.take(e->device, e->res_cus, e->res_kind == 2 ? e->bc.nwg : e->rc.nwg);
     const long long burst = std::min<long long>(remaining, (e->calibrated || resident) ? 128 : 2);
     TR2(e, "launch burst=%lld K=%d", burst, e->K);
     // `burst` ADMM iterations = burst / segs graphs of `segs` segments + single-segment graphs for the rest
@@ -4195,7 +4215,7 @@ extern "C" int hipeng_time_kernel(hipeng *e, int which, int reps, double *usec) 
   if (which == 8 && !(e->res_on && e->res_fails < 3)) return HIPENG_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));
   CuLease lease;
-  if (which == 8 && e->res_kind != 3) lease.take(e->device, e->res_cus, e->res_kind == 2 ? e->bc.nwg : e->rc.nwg);
+  if (which == 8 && e->res_kind < 3) lease.take(e->device, e->res_cus, e->res_kind == 2 ? e->bc.nwg : e->rc.nwg);
   auto one = [&](int it) {
     // the first two kernels of a resident ADMM iteration: right-hand side + start residual, then the whole linear solve
     // (without k_admm_finalize the iterates do not move: every repetition solves the same system from the same start)
@@ -4301,6 +4321,7 @@ extern "C" int hipeng_resident_info(hipeng *e, long long out[16]) {
   out[12] = std::max<long long>(e->res_slow_max, s.res_slow_max); out[13] = e->res_repub + s.res_repub; out[14] = e->res_fails; out[15] = e->res_kind == 3 ? e->bd.kc : 0;
   if (e->res_kind == 2) { out[2] = 64; out[3] = e->bc.nwg; out[4] = 0; out[5] = 0; }
   if (e->res_kind == 3) { out[2] = 0; out[3] = e->c.dP.nblk; out[4] = 0; out[5] = 0; }
+  if (e->res_kind == 4) { out[2] = 0; out[3] = e->dd.na; out[4] = (long long)e->dd.nap * e->dd.nap; out[5] = 0; out[15] = e->dd.nb2; }
   return 0;
 }
 
