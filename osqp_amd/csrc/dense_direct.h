@@ -32,17 +32,18 @@ struct DdCtx {
   const int *drow;          // [nd] row of A
   const char *isdense;      // [m] 1: the row is in R
   double *rr, *vv;          // [nap] reduced residual, solution
-  double *D, *Bp, *T;       // inversion: pivot block inverse [128][128], packed row panel [128][nap], transposed column panel [128][nap]
+  double *D, *Bp, *T;       // inversion: pivot block inverse [128][128], transposed column panel W' [128][nap], swept panel (W D)' [128][nap]
   int *flag;                // [0] a pivot was not positive
 };
 
 // C = beta C + alpha T' diag(w) B on v_mfma_f64_16x16x4_f64.  T: [K][ldt] (so the A operand A[i][k] = T[k][i] is 4 rows x 16
 // contiguous doubles per wave load), B: [K][ldb], C: [M][ldc].  Workgroup = 128 x 128 of C, wavefront = 64 x 64 = 4 x 4 tiles.
-// Tiles whose rows lie in [sr0, sr1) or columns in [sc0, sc1) are left alone (the pivot block row / column of a Gauss-Jordan step).
+// Tiles whose rows lie in [sr0, sr1) or columns in [sc0, sc1) are left alone (the pivot block row / column of a sweep step).
 __global__ void __launch_bounds__(TB) k_dd_gemm_tn(double *C, int ldc, const double *T, int ldt, const double *B, int ldb, const double *w,
-                                                   int M, int N, int K, double alpha, double beta, int sr0, int sr1, int sc0, int sc1) {
+                                                   int M, int N, int K, double alpha, double beta, int sr0, int sr1, int sc0, int sc1, int lower) {
   const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;
   if ((row0 >= sr0 && row0 < sr1) || (col0 >= sc0 && col0 < sc1)) return;
+  if (lower && col0 > row0) return;            // symmetric result: the tiles on and below the diagonal only (k_dd_mirror fills the rest)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
   const int wr = row0 + (wv >> 1) * 64, wc = col0 + (wv & 1) * 64;
   mfma_d4 acc[4][4];
@@ -127,52 +128,79 @@ __global__ void __launch_bounds__(INV_TB) k_dd_pivot(const double *A, int lda, i
   }
   for (int i = i0; i < DD_NB; i += RS) D[i * DD_NB + j] = bl[i * DD_NB + j];
 }
-// Bp = row panel kb of A (packed [128][n]); T = column panel kb transposed ([128][n]): 64 rows of A per workgroup through LDS
-__global__ void __launch_bounds__(TB) k_dd_panels(const double *A, int lda, int n, int kb, double *Bp, double *T) {
+// Wt = column panel kb of A transposed ([128][n], from the lower triangle: rows below the pivot block from the column panel itself,
+// columns left of it from the row panel -- the matrix is symmetric and only its lower tiles are kept up to date): 64 rows per workgroup
+__global__ void __launch_bounds__(TB) k_dd_panel(const double *A, int lda, int n, int kb, double *Wt) {
   __shared__ double tile[64][DD_NB + 1];
-  const int i0 = blockIdx.x * 64;
-  for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) {
-    const int i = q / DD_NB, r = q % DD_NB;
-    tile[i][r] = i0 + i < n ? A[(size_t)(i0 + i) * lda + (size_t)kb * DD_NB + r] : 0.0;
-  }
-  __syncthreads();
-  for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) {
-    const int r = q / 64, i = q % 64;
-    if (i0 + i < n) T[(size_t)r * n + i0 + i] = tile[i][r];
-  }
-  // this workgroup's 64 columns of the row panel
-  for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) {
-    const int r = q / 64, jx = q % 64;
-    if (i0 + jx < n) Bp[(size_t)r * n + i0 + jx] = A[((size_t)kb * DD_NB + r) * lda + i0 + jx];
+  const int i0 = blockIdx.x * 64, p0 = kb * DD_NB;
+  if (i0 >= p0) {                        // at or below the pivot block: A[i][p0 + r], transposed through LDS
+    for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) {
+      const int i = q / DD_NB, r = q % DD_NB;
+      tile[i][r] = i0 + i < n ? A[(size_t)(i0 + i) * lda + p0 + r] : 0.0;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) {
+      const int r = q / 64, i = q % 64;
+      if (i0 + i < n) Wt[(size_t)r * n + i0 + i] = tile[i][r];
+    }
+  } else {                               // left of it: A[i][p0 + r] = A[p0 + r][i], rows of the row panel
+    for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) {
+      const int r = q / 64, i = q % 64;
+      Wt[(size_t)r * n + i0 + i] = A[(size_t)(p0 + r) * lda + i0 + i];
+    }
   }
 }
-__global__ void __launch_bounds__(TB) k_dd_setblock(double *A, int lda, int kb, const double *D) {
-  for (int q = blockIdx.x * TB + threadIdx.x; q < DD_NB * DD_NB; q += gridDim.x * TB)
-    A[((size_t)kb * DD_NB + q / DD_NB) * lda + (size_t)kb * DD_NB + q % DD_NB] = D[q];
+// the swept pivot block and panel back into the lower triangle: A_kk = -D, A[i][p0 + c] = V[c][i] below, A[p0 + r][j] = V[r][j] left
+__global__ void __launch_bounds__(TB) k_dd_store_panel(double *A, int lda, int n, int kb, const double *Vt, const double *D) {
+  __shared__ double tile[DD_NB][64 + 1];
+  const int i0 = blockIdx.x * 64, p0 = kb * DD_NB;
+  if (i0 >= p0 + DD_NB) {
+    for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) { const int r = q / 64, i = q % 64; tile[r][i] = i0 + i < n ? Vt[(size_t)r * n + i0 + i] : 0.0; }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) { const int i = q / DD_NB, r = q % DD_NB; if (i0 + i < n) A[(size_t)(i0 + i) * lda + p0 + r] = tile[r][i]; }
+  } else if (i0 + 64 <= p0) {
+    for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) { const int r = q / 64, i = q % 64; A[(size_t)(p0 + r) * lda + i0 + i] = Vt[(size_t)r * n + i0 + i]; }
+  } else {                               // the pivot block itself (two workgroups, 64 columns each)
+    for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) { const int r = q / 64, i = q % 64; A[(size_t)(p0 + r) * lda + i0 + i] = -D[r * DD_NB + (i0 - p0) + i]; }
+  }
+}
+// upper = lower' (and the whole matrix negated when neg: the sweep leaves -A^-1)
+__global__ void __launch_bounds__(TB) k_dd_mirror(double *A, int n, int neg) {
+  __shared__ double tile[64][65];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  const double sg = neg ? -1.0 : 1.0;
+  for (int q = threadIdx.x; q < 64 * 64; q += TB) { const int i = q / 64, j = q % 64; tile[i][j] = sg * A[(size_t)(bi * 64 + i) * n + bj * 64 + j]; }
+  __syncthreads();
+  if (neg) for (int q = threadIdx.x; q < 64 * 64; q += TB) { const int i = q / 64, j = q % 64; if (bi != bj || j <= i) A[(size_t)(bi * 64 + i) * n + bj * 64 + j] = tile[i][j]; }
+  for (int q = threadIdx.x; q < 64 * 64; q += TB) { const int j = q / 64, i = q % 64; if (bi != bj || j < i) A[(size_t)(bj * 64 + j) * n + bi * 64 + i] = tile[i][j]; }
 }
 
-// A (n x n, n a multiple of 128, symmetric positive definite) <- A^-1 in place on `stream`.  Per pivot block: invert it (D), pack
-// the row panel and the transposed column panel, then  row panel = D Bp;  everything else -= T' (row panel);  column panel = -T' D.
-static int dd_invert(hipStream_t stream, double *A, int n, double *D, double *Bp, double *T, int *flag) {
+// A (n x n, n a multiple of 128, symmetric positive definite, lower tiles valid) <- A^-1 in place on `stream`, by symmetric block sweeps
+// (Beaton's sweep operator in blocks: half the flops of Gauss-Jordan, everything stays symmetric).  Per pivot block k:
+//   D = A_kk^-1 (LDS);  W = column panel k (packed transposed, Wt);  V = W D (Vt = D Wt: one 128 x n GEMM);
+//   A_ij -= V_i W_j' for the lower tiles outside block row / column k (one GEMM);  panel <- V;  A_kk <- -D.
+// All pivots swept: A = -(A^-1); mirrored and negated at the end.
+static int dd_invert(hipStream_t stream, double *A, int n, double *D, double *Wt, double *Vt, int *flag) {
   static bool lds_set = false;
   if (!lds_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dd_pivot), hipFuncAttributeMaxDynamicSharedMemorySize, DD_NB * DD_NB * (int)sizeof(double)) != hipSuccess) return HIPENG_ERR_HIP;
     lds_set = true;
   }
   const int nb = n / DD_NB;
-  const dim3 gfull(nb, nb), grow(nb, 1), gcol(1, nb);
   for (int kb = 0; kb < nb; kb++) {
     const int p0 = kb * DD_NB, p1 = p0 + DD_NB;
     hipLaunchKernelGGL(k_dd_pivot, dim3(1), dim3(INV_TB), DD_NB * DD_NB * sizeof(double), stream, (const double *)A, n, kb, D, flag);
-    hipLaunchKernelGGL(k_dd_panels, dim3((n + 63) / 64), dim3(TB), 0, stream, (const double *)A, n, n, kb, Bp, T);
-    hipLaunchKernelGGL(k_dd_gemm_tn, grow, dim3(TB), 0, stream, A + (size_t)p0 * n, n, (const double *)D, DD_NB, (const double *)Bp, n, (const double *)nullptr,
-                       DD_NB, n, DD_NB, 1.0, 0.0, -1, -1, p0, p1);
-    hipLaunchKernelGGL(k_dd_gemm_tn, gfull, dim3(TB), 0, stream, A, n, (const double *)T, n, (const double *)(A + (size_t)p0 * n), n, (const double *)nullptr,
-                       n, n, DD_NB, -1.0, 1.0, p0, p1, p0, p1);
-    hipLaunchKernelGGL(k_dd_gemm_tn, gcol, dim3(TB), 0, stream, A + p0, n, (const double *)T, n, (const double *)D, DD_NB, (const double *)nullptr,
-                       n, DD_NB, DD_NB, -1.0, 0.0, p0, p1, -1, -1);
-    hipLaunchKernelGGL(k_dd_setblock, dim3(16), dim3(TB), 0, stream, A, n, kb, (const double *)D);
+    hipLaunchKernelGGL(k_dd_panel, dim3(n / 64), dim3(TB), 0, stream, (const double *)A, n, n, kb, Wt);
+    // Vt[c][i] = sum_r D[r][c] Wt[r][i]  (D symmetric)
+    hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nb, 1), dim3(TB), 0, stream, Vt, n, (const double *)D, DD_NB, (const double *)Wt, n, (const double *)nullptr,
+                       DD_NB, n, DD_NB, 1.0, 0.0, -1, -1, p0, p1, 0);
+    // A[i][j] -= sum_c Vt[c][i] Wt[c][j]
+    hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nb, nb), dim3(TB), 0, stream, A, n, (const double *)Vt, n, (const double *)Wt, n, (const double *)nullptr,
+                       n, n, DD_NB, -1.0, 1.0, p0, p1, p0, p1, 1);
+    hipLaunchKernelGGL(k_dd_store_panel, dim3(n / 64), dim3(TB), 0, stream, A, n, n, kb, (const double *)Vt, (const double *)D);
   }
+  hipLaunchKernelGGL(k_dd_mirror, dim3(n / 64, n / 64), dim3(TB), 0, stream, A, n, 1);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -254,7 +282,15 @@ __global__ void __launch_bounds__(TB) k_dd_gemv(Ctx c, DdCtx dd) {
     const double2 *src = reinterpret_cast<const double2 *>(dd.S + (size_t)row * nap);
     const double2 *x2 = reinterpret_cast<const double2 *>(xs);
     double s0 = 0.0, s1 = 0.0;
-    for (int q = lane; q < nap / 2; q += 64) { const double2 v = src[q], x = x2[q]; s0 += v.x * x.x; s1 += v.y * x.y; }
+    int q = lane;
+    for (; q + 7 * 64 < nap / 2; q += 8 * 64) {              // eight 16-byte loads in flight per lane
+      double2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[q + 64 * u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const double2 x = x2[q + 64 * u]; s0 += v[u].x * x.x; s1 += v[u].y * x.y; }
+    }
+    for (; q < nap / 2; q += 64) { const double2 v = src[q], x = x2[q]; s0 += v.x * x.x; s1 += v.y * x.y; }
     const double s = wave_sum(s0 + s1);
     if (lane == 0) dd.vv[row] = s;
   }
