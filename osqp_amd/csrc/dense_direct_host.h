@@ -71,6 +71,7 @@ static int build_dense_direct(hipeng *e, const csc *P, const csc *A) {
   }
   e->dd = dd;
   e->c.init_r = e->c.r; e->c.init_stride = 1;
+  e->c.fin_wave_rows = 1;
   e->res_kind = 4; e->res_on = e->res_use = true;
   if (e->trace) fprintf(stderr, "[osqp_amd] dense-direct solve: %d dense unknowns (%d x %d inverse, %.0f MB), %d sparse unknowns by Schur complement, %d dense rows of A\n",
                         na, nap, nap, 8e-6 * nap * nap, nb2, nd);

@@ -150,6 +150,7 @@ struct Ctx {             // static pointers / sizes, passed by value
   double *pdir, *ut;               // Chronopoulos-Gear PCG: p, [u|t]
   G4     *g4;                      // ... and {r, w, s, Minv} records, ping-ponged on parity (2n)
   int     init_stride;             // element stride of init_r (4 when it points into g4)
+  int     fin_wave_rows;           // k_admm_finalize: one wavefront per long row of A (dense-direct engines)
   // resident PCG: k_pcg_init also leaves u0 = Minv r0 in the layout of the exchanged vector (position u0map[j] of u0pos), so that
   // the resident launch takes it in with one coalesced sweep instead of a 2-byte-indexed gather (null: not a k_pcg_resident engine)
   const unsigned short *u0map;
@@ -1020,6 +1021,17 @@ __global__ void __launch_bounds__(TB) k_admm_finalize(Ctx c) {
   // long rows: the whole workgroup per row.  (One wavefront per row as in the PCG kernels is twice as fast on the Lasso's 10 000 rows
   // -- 2 % of its ADMM iteration -- but z~ then differs in its last bits, and a solve at the floor of attainable accuracy
   // (test_tight_tolerance_on_ill_conditioned_system, eps = 1e-9 on a cond 1e6 system) moved from 225 to 325 iterations: not worth it.)
+  if (c.fin_wave_rows) {
+    // dense-direct engines (dense_direct.h): one wavefront per long row with the PCG kernels' row dot -- there this pass is
+    // 40 % of an ADMM iteration (72 -> 2x us at the Lasso's 10 000 rows), and the linear solves no longer stop on a residual
+    // that the last bits of z~ could move
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int bi = c.A.nstream + blockIdx.x * (TB / 64) + wv; bi < c.A.nwave; bi += gridDim.x * (TB / 64)) {
+      const RowBlk lb = c.A.blk[bi];
+      const double zt = wave_row_dot(c.A, lb.k0, lb.k1, [&](int cc) { return xts[cc]; });
+      if (lane == 0) row_update(lb.r0, zt);
+    }
+  } else
   for (int bi = c.A.nstream + blockIdx.x; bi < c.A.nwave; bi += gridDim.x) {
     const RowBlk lb = c.A.blk[bi];
     const double zt = long_row_dot(c.A, lb.k0, lb.k1, xts, red);
