@@ -20,6 +20,9 @@
 #define DD_MAX 8192
 #define DD_NBR 8
 #define DD_DENSE_ROW 32
+#ifndef DD_CH
+#define DD_CH 2           // MFMA steps per prefetched chunk of k_dd_gemm_tn
+#endif
 
 struct DdCtx {
   int na, nap, nb2, nd;
@@ -39,9 +42,9 @@ struct DdCtx {
 // C = beta C + alpha T' diag(w) B on v_mfma_f64_16x16x4_f64.  T: [K][ldt] (so the A operand A[i][k] = T[k][i] is 4 rows x 16
 // contiguous doubles per wave load), B: [K][ldb], C: [M][ldc].  Workgroup = 128 x 128 of C, wavefront = 64 x 64 = 4 x 4 tiles.
 // Tiles whose rows lie in [sr0, sr1) or columns in [sc0, sc1) are left alone (the pivot block row / column of a sweep step).
-__global__ void __launch_bounds__(TB) k_dd_gemm_tn(double *C, int ldc, const double *T, int ldt, const double *B, int ldb, const double *w,
+__global__ void __launch_bounds__(TB, 2) k_dd_gemm_tn(double *C, int ldc, const double *T, int ldt, const double *B, int ldb, const double *w,
                                                    int M, int N, int K, double alpha, double beta, int sr0, int sr1, int sc0, int sc1, int lower) {
-  const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;
+  const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;      // (tried: an XCD-contiguous workgroup -> tile map; 24.9 -> 23.9 TFLOP/s, the sweep 21.6 -> 26.9 ms)
   if ((row0 >= sr0 && row0 < sr1) || (col0 >= sc0 && col0 < sc1)) return;
   if (lower && col0 > row0) return;            // symmetric result: the tiles on and below the diagonal only (k_dd_mirror fills the rest)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
@@ -51,12 +54,11 @@ __global__ void __launch_bounds__(TB) k_dd_gemm_tn(double *C, int ldc, const dou
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-  // K in chunks of 16 (four MFMA steps): the 32 operand loads of the NEXT chunk are issued before the 64 MFMAs of this one
-  // (one wavefront per SIMD at 128 accumulator registers: nothing else hides the L2 round trip)
-  double a[4][4], b[4][4], an[4][4], bn[4][4];
-  auto load = [&](int k0, double (&aa)[4][4], double (&bb)[4][4]) {
+  // K in chunks of DD_CH MFMA steps (4 k each): the operand loads of the NEXT chunk are issued before the MFMAs of this one
+  double a[DD_CH][4], b[DD_CH][4], an[DD_CH][4], bn[DD_CH][4];
+  auto load = [&](int k0, double (&aa)[DD_CH][4], double (&bb)[DD_CH][4]) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < DD_CH; ++s) {
       const int kk = k0 + 4 * s + lk;
       const bool kv = kk < K;
       const double wk = (w && kv) ? w[kk] : 1.0;
@@ -69,16 +71,16 @@ __global__ void __launch_bounds__(TB) k_dd_gemm_tn(double *C, int ldc, const dou
     }
   };
   load(0, a, b);
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    if (k0 + 16 < K) load(k0 + 16, an, bn);
+  for (int k0 = 0; k0 < K; k0 += 4 * DD_CH) {
+    if (k0 + 4 * DD_CH < K) load(k0 + 4 * DD_CH, an, bn);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < DD_CH; ++s)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < DD_CH; ++s)
 #pragma unroll
       for (int t = 0; t < 4; ++t) { a[s][t] = an[s][t]; b[s][t] = bn[s][t]; }
   }
