@@ -207,7 +207,7 @@ def other_configs(eps):
                 us_l = t_pair.value - t_init.value
                 out[name]["pcg_kernels_note"] = "launch-per-step kernels, timed for reference; the solve above used resident launches"
                 out[name]["resident_launch"] = dict(form={2: "k_pcg_blockres", 3: "k_blk_apply + k_blk_finish (block-direct)",
-                                                          4: "k_dd_gather + k_dd_reduce + k_dd_gemv + k_dd_finish (dense-direct)"}.get(int(info[9]), "k_pcg_resident"), usec=round(us_l, 1),
+                                                          4: "k_dd_gather + k_dd_gemv + k_dd_finish (dense-direct)"}.get(int(info[9]), "k_pcg_resident"), usec=round(us_l, 1),
                                                     pcg_iterations=int(info[6]), usec_per_pcg_iteration=round(us_l / max(1, int(info[6])), 2),
                                                     bytes_read_once_per_launch_MB=round((s.nnzP * 2 - s.n) * 8 / 1e6, 1) if info[9] == 2 else None)
                 if info[9] == 4:

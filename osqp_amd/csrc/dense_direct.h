@@ -14,7 +14,7 @@
 //   formation (dd_refresh):  S = R' diag(w) R  over the dense rows of A (R: n_d x n_a, built from the CSR rows; one TN GEMM on
 //     v_mfma_f64_16x16x4_f64) + the short rows, P and sigma scattered with atomics + the Schur terms; then the explicit inverse by
 //     blocked Gauss-Jordan (128-wide pivot blocks inverted in LDS, every other flop in the same GEMM kernel).
-//   solve (launch_dense_direct): k_dd_reduce -> k_dd_gemv (v_a = S^-1 r_a, HBM-bound) -> k_dd_finish, applied to the residual
+//   solve (launch_dense_direct): k_dd_gather -> k_dd_gemv (v_a = S^-1 r_a, HBM-bound) -> k_dd_finish, applied to the residual
 //     r0 = b - K x~0 that k_pcg_init forms (refinement form, as the block-direct solve).
 #define DD_NB 128
 #define DD_MAX 8192
@@ -30,6 +30,7 @@ struct DdCtx {
   const int *alist, *blist; // [na], [nb2] variable of a dense index / of a B2 index
   const int *bnbr;          // [nb2][DD_NBR] dense indices of a B2 variable's neighbours (-1: none)
   double *bval, *bdiag;     // [nb2][DD_NBR] K(b, neighbour), [nb2] K(b, b)
+  const int *aptr; const int2 *aadj;   // the same adjacency from the dense side: for dense index a the pairs {b, slot} with bnbr[b][slot] == a
   double *S;                // [nap][nap] Schur complement, then its inverse
   double *R, *dw;           // [nd][nap] dense rows of A over the dense unknowns; [nd] their weights rho~
   const int *drow;          // [nd] row of A
@@ -217,59 +218,63 @@ __global__ void __launch_bounds__(TB) k_dd_fill_R(Ctx c, DdCtx dd) {
   }
   if (threadIdx.x == 0) dd.dw[d] = c.rhoe[i];
 }
-__device__ __forceinline__ void dd_add_pair(const DdCtx &dd, int cp, int cq, double v, bool same) {
-  if (cp >= 0) { if (cq >= 0) atomicAdd(dd.S + (size_t)cp * dd.nap + cq, v); return; }
-  if (cp == -1) return;
-  const int b = -cp - 2;
-  if (same) { atomicAdd(dd.bdiag + b, v); return; }
-  if (cq < 0) return;
-  for (int s = 0; s < DD_NBR; ++s) if (dd.bnbr[b * DD_NBR + s] == cq) { atomicAdd(dd.bval + b * DD_NBR + s, v); return; }
-}
-// the short rows of A (one thread each: every pair of its entries), then P and sigma (one thread per variable)
+// The short rows of A, P and sigma: one thread per unknown j adds up its OWN row of S (or its own B2 record) -- every entry has one
+// writer and a fixed summation order (the order of M's row j, then of each row of A), so the formed matrix, its inverse and the
+// iterates are bit-reproducible; no atomics.
 __global__ void __launch_bounds__(TB) k_dd_scatter(Ctx c, DdCtx dd) {
   const double sigma = c.prm->sigma;
-  for (int i = blockIdx.x * TB + threadIdx.x; i < c.m; i += gridDim.x * TB) {
-    if (dd.isdense[i]) continue;
-    const double w = c.rhoe[i];
-    for (int p = c.A.rowptr[i]; p < c.A.rowptr[i + 1]; ++p) {
-      const int cp = dd.vidx[c.A.col[p]];
-      if (cp == -1) continue;
-      const double ap = w * c.A.val[p];
-      for (int q = c.A.rowptr[i]; q < c.A.rowptr[i + 1]; ++q) dd_add_pair(dd, cp, dd.vidx[c.A.col[q]], ap * c.A.val[q], p == q);
-    }
-  }
   for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
     const int cj = dd.vidx[j];
     if (cj == -1) continue;
-    dd_add_pair(dd, cj, cj, sigma, true);
-    for (int k = c.M.rowptr[j]; k < c.M.split[j]; ++k) dd_add_pair(dd, cj, dd.vidx[c.M.col[k]], c.M.val[k], c.M.col[k] == j);
+    double *row = cj >= 0 ? dd.S + (size_t)cj * dd.nap : nullptr;
+    const int b = -cj - 2;
+    double diag = sigma;                                    // (B2: the diagonal entry; dense: added to row[cj] below)
+    for (int k = c.M.rowptr[j]; k < c.M.split[j]; ++k) {    // P
+      const int col = c.M.col[k], cq = dd.vidx[col];
+      if (col == j) diag += c.M.val[k];
+      else if (row && cq >= 0) row[cq] += c.M.val[k];
+    }
+    for (int k = c.M.split[j]; k < c.M.rowptr[j + 1]; ++k) {   // rows of A that hold j
+      const int i = c.M.col[k] - c.n;
+      if (dd.isdense[i]) continue;
+      const double wa = c.rhoe[i] * c.M.val[k];
+      for (int q = c.A.rowptr[i]; q < c.A.rowptr[i + 1]; ++q) {
+        const int col = c.A.col[q], cq = dd.vidx[col];
+        const double v = wa * c.A.val[q];
+        if (col == j) diag += v;
+        else if (cq < 0) continue;
+        else if (row) row[cq] += v;
+        else for (int s2 = 0; s2 < DD_NBR; ++s2) if (dd.bnbr[b * DD_NBR + s2] == cq) { dd.bval[b * DD_NBR + s2] += v; break; }
+      }
+    }
+    if (row) row[cj] += diag; else dd.bdiag[b] = diag;
   }
 }
-// S -= K_aB D^-1 K_Ba (one thread per B2 variable); the padding rows get a unit diagonal
+// S -= K_aB D^-1 K_Ba, row a by its own thread (through the adjacency seen from the dense side); the padding rows get a unit diagonal
 __global__ void __launch_bounds__(TB) k_dd_schur(DdCtx dd) {
-  for (int b = blockIdx.x * TB + threadIdx.x; b < dd.nb2; b += gridDim.x * TB) {
-    const double di = 1.0 / dd.bdiag[b];
-    if (!(dd.bdiag[b] > 0.0)) atomicOr(dd.flag, 1);
-    for (int s = 0; s < DD_NBR; ++s) {
-      const int as = dd.bnbr[b * DD_NBR + s];
-      if (as < 0) continue;
-      const double vs = dd.bval[b * DD_NBR + s] * di;
-      for (int t = 0; t < DD_NBR; ++t) { const int at = dd.bnbr[b * DD_NBR + t]; if (at >= 0) atomicAdd(dd.S + (size_t)as * dd.nap + at, -vs * dd.bval[b * DD_NBR + t]); }
+  for (int b = blockIdx.x * TB + threadIdx.x; b < dd.nb2; b += gridDim.x * TB) if (!(dd.bdiag[b] > 0.0)) atomicOr(dd.flag, 1);
+  for (int a = blockIdx.x * TB + threadIdx.x; a < dd.nap; a += gridDim.x * TB) {
+    double *row = dd.S + (size_t)a * dd.nap;
+    if (a >= dd.na) { row[a] = 1.0; continue; }
+    for (int k = dd.aptr[a]; k < dd.aptr[a + 1]; ++k) {
+      const int b = dd.aadj[k].x;
+      const double f = dd.bval[b * DD_NBR + dd.aadj[k].y] / dd.bdiag[b];
+      for (int t = 0; t < DD_NBR; ++t) { const int at = dd.bnbr[b * DD_NBR + t]; if (at >= 0) row[at] -= f * dd.bval[b * DD_NBR + t]; }
     }
   }
-  for (int a = dd.na + blockIdx.x * TB + threadIdx.x; a < dd.nap; a += gridDim.x * TB) dd.S[(size_t)a * dd.nap + a] = 1.0;
 }
 
 // ---- solve ----------------------------------------------------------------------------------------------------------------
+// rr = r_a - K_aB D^-1 r_B: the residual on the dense unknowns, minus what the B2 unknowns' rows contribute (fixed order: no atomics)
 __global__ void __launch_bounds__(TB) k_dd_gather(Ctx c, DdCtx dd) {
   { const State *st = c.st; if (st->stalled || !st->run) return; }
-  for (int a = blockIdx.x * TB + threadIdx.x; a < dd.nap; a += gridDim.x * TB) dd.rr[a] = a < dd.na ? c.init_r[dd.alist[a]] : 0.0;
-}
-__global__ void __launch_bounds__(TB) k_dd_reduce(Ctx c, DdCtx dd) {
-  { const State *st = c.st; if (st->stalled || !st->run) return; }
-  for (int b = blockIdx.x * TB + threadIdx.x; b < dd.nb2; b += gridDim.x * TB) {
-    const double rb = c.init_r[dd.blist[b]] / dd.bdiag[b];
-    for (int s = 0; s < DD_NBR; ++s) { const int a = dd.bnbr[b * DD_NBR + s]; if (a >= 0) atomicAdd(dd.rr + a, -dd.bval[b * DD_NBR + s] * rb); }
+  for (int a = blockIdx.x * TB + threadIdx.x; a < dd.nap; a += gridDim.x * TB) {
+    double v = 0.0;
+    if (a < dd.na) {
+      v = c.init_r[dd.alist[a]];
+      for (int k = dd.aptr[a]; k < dd.aptr[a + 1]; ++k) { const int b = dd.aadj[k].x; v -= dd.bval[b * DD_NBR + dd.aadj[k].y] * (c.init_r[dd.blist[b]] / dd.bdiag[b]); }
+    }
+    dd.rr[a] = v;
   }
 }
 // vv = S^-1 rr: one wavefront per row of the (symmetric) inverse, the vector in LDS; 210 MB at n_a = 5 000 -- the pass that bounds a solve

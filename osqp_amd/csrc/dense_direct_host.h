@@ -52,19 +52,30 @@ static int build_dense_direct(hipeng *e, const csc *P, const csc *A) {
   if (!pays) return 0;
   std::vector<int> bnbr(bnbr_var.size());
   for (size_t q = 0; q < bnbr_var.size(); q++) bnbr[q] = bnbr_var[q] < 0 ? -1 : vidx[bnbr_var[q]];
+  // the adjacency seen from the dense side: for dense index a the {b, slot} pairs with bnbr[b][slot] == a, b ascending
+  std::vector<int> aptr((size_t)nap + 1, 0);
+  std::vector<int2> aadj;
+  {
+    std::vector<int> cnt((size_t)nap, 0);
+    for (size_t q = 0; q < bnbr.size(); q++) if (bnbr[q] >= 0) cnt[bnbr[q]]++;
+    for (int a = 0; a < nap; a++) aptr[a + 1] = aptr[a] + cnt[a];
+    aadj.resize((size_t)aptr[nap]);
+    std::vector<int> pos(aptr.begin(), aptr.end() - 1);
+    for (size_t q = 0; q < bnbr.size(); q++) if (bnbr[q] >= 0) aadj[pos[bnbr[q]]++] = int2{(int)(q / DD_NBR), (int)(q % DD_NBR)};
+  }
   DdCtx dd{};
   dd.na = na; dd.nap = nap; dd.nb2 = nb2; dd.nd = nd;
-  int *d_vidx = nullptr, *d_alist = nullptr, *d_blist = nullptr, *d_bnbr = nullptr, *d_drow = nullptr; char *d_isdense = nullptr;
+  int *d_vidx = nullptr, *d_alist = nullptr, *d_blist = nullptr, *d_bnbr = nullptr, *d_drow = nullptr, *d_aptr = nullptr; int2 *d_aadj = nullptr; char *d_isdense = nullptr;
   if (dev_alloc(e, &d_vidx, (size_t)n) || dev_alloc(e, &d_alist, (size_t)na) || dev_alloc(e, &d_blist, (size_t)nb2) || dev_alloc(e, &d_bnbr, bnbr.size()) ||
-      dev_alloc(e, &d_drow, (size_t)nd) || dev_alloc(e, &d_isdense, (size_t)m) || dev_alloc(e, &dd.bval, bnbr.size()) || dev_alloc(e, &dd.bdiag, (size_t)nb2) ||
+      dev_alloc(e, &d_drow, (size_t)nd) || dev_alloc(e, &d_aptr, aptr.size()) || dev_alloc(e, &d_aadj, aadj.size()) || dev_alloc(e, &d_isdense, (size_t)m) || dev_alloc(e, &dd.bval, bnbr.size()) || dev_alloc(e, &dd.bdiag, (size_t)nb2) ||
       dev_alloc(e, &dd.S, (size_t)nap * nap) || dev_alloc(e, &dd.R, (size_t)nd * nap) || dev_alloc(e, &dd.dw, (size_t)nd) || dev_alloc(e, &dd.rr, (size_t)nap) ||
       dev_alloc(e, &dd.vv, (size_t)nap) || dev_alloc(e, &dd.D, (size_t)DD_NB * DD_NB) || dev_alloc(e, &dd.Bp, (size_t)DD_NB * nap) || dev_alloc(e, &dd.T, (size_t)DD_NB * nap) ||
       dev_alloc(e, &dd.flag, (size_t)4)) return HIPENG_ERR_HIP;
 #define DDUP(dst, src) if (!(src).empty()) HIPCHK(hipMemcpyAsync(dst, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, e->stream))
-  DDUP(d_vidx, vidx); DDUP(d_alist, alist); DDUP(d_blist, blist); DDUP(d_bnbr, bnbr); DDUP(d_drow, drow); DDUP(d_isdense, isdense);
+  DDUP(d_vidx, vidx); DDUP(d_alist, alist); DDUP(d_blist, blist); DDUP(d_bnbr, bnbr); DDUP(d_drow, drow); DDUP(d_isdense, isdense); DDUP(d_aptr, aptr); DDUP(d_aadj, aadj);
 #undef DDUP
   HIPCHK(hipStreamSynchronize(e->stream));        // (the sources are locals)
-  dd.vidx = d_vidx; dd.alist = d_alist; dd.blist = d_blist; dd.bnbr = d_bnbr; dd.drow = d_drow; dd.isdense = d_isdense;
+  dd.vidx = d_vidx; dd.alist = d_alist; dd.blist = d_blist; dd.bnbr = d_bnbr; dd.drow = d_drow; dd.isdense = d_isdense; dd.aptr = d_aptr; dd.aadj = d_aadj;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dd_gemv), hipFuncAttributeMaxDynamicSharedMemorySize, nap * (int)sizeof(double)) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
@@ -94,7 +105,7 @@ static int dd_refresh(hipeng *e) {
     hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nap / 128, nap / 128), dim3(TB), 0, e->stream, dd.S, nap, (const double *)dd.R, nap, (const double *)dd.R, nap, (const double *)dd.dw,
                        nap, nap, dd.nd, 1.0, 0.0, -1, -1, -1, -1, 1);
   }
-  hipLaunchKernelGGL(k_dd_scatter, dim3(elem_grid(std::max(e->n, e->m))), dim3(TB), 0, e->stream, e->c, dd);
+  hipLaunchKernelGGL(k_dd_scatter, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c, dd);
   hipLaunchKernelGGL(k_dd_schur, dim3(elem_grid(std::max(1, std::max(dd.nb2, nap)))), dim3(TB), 0, e->stream, dd);
   if (int rc = dd_invert(e->stream, dd.S, nap, dd.D, dd.Bp, dd.T, dd.flag)) return rc;
   HIPCHK(hipGetLastError());
@@ -104,7 +115,6 @@ static int dd_refresh(hipeng *e) {
 static void launch_dense_direct(hipeng *e) {
   const DdCtx &dd = e->dd;
   hipLaunchKernelGGL(k_dd_gather, dim3(elem_grid(dd.nap)), dim3(TB), 0, e->stream, e->c, dd);
-  if (dd.nb2) hipLaunchKernelGGL(k_dd_reduce, dim3(elem_grid(dd.nb2)), dim3(TB), 0, e->stream, e->c, dd);
   hipLaunchKernelGGL(k_dd_gemv, dim3(std::min(1024, dd.nap / 4)), dim3(TB), (size_t)dd.nap * sizeof(double), e->stream, e->c, dd);
   hipLaunchKernelGGL(k_dd_finish, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c, dd);
 }
