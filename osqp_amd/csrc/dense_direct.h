@@ -32,6 +32,7 @@ struct DdCtx {
   double *bval, *bdiag;     // [nb2][DD_NBR] K(b, neighbour), [nb2] K(b, b)
   const int *aptr; const int2 *aadj;   // the same adjacency from the dense side: for dense index a the pairs {b, slot} with bnbr[b][slot] == a
   double *S;                // [nap][nap] Schur complement, then its inverse
+  double *S0;               // [nap][nap] the Schur complement as formed (both triangles): the check of every fresh inverse multiplies by it
   double *R, *dw;           // [nd][nap] dense rows of A over the dense unknowns; [nd] their weights rho~
   const int *drow;          // [nd] row of A
   const char *isdense;      // [m] 1: the row is in R
@@ -277,30 +278,44 @@ __global__ void __launch_bounds__(TB) k_dd_gather(Ctx c, DdCtx dd) {
     dd.rr[a] = v;
   }
 }
-// vv = S^-1 rr: one wavefront per row of the (symmetric) inverse, the vector in LDS; 210 MB at n_a = 5 000 -- the pass that bounds a solve
-__global__ void __launch_bounds__(TB) k_dd_gemv(Ctx c, DdCtx dd) {
-  { const State *st = c.st; if (st->stalled || !st->run) return; }
+// y = Mx x for a symmetric nap x nap matrix: one wavefront per row, eight 16-byte loads in flight per lane, the vector in LDS.
+// With Mx = S^-1 this is the pass that bounds a solve (210 MB at n_a = 5 000).
+__global__ void __launch_bounds__(TB) k_dd_gemv(Ctx c, int nap, const double *Mx, const double *x, double *y, int gated) {
+  if (gated) { const State *st = c.st; if (st->stalled || !st->run) return; }
   extern __shared__ __attribute__((aligned(16))) double xs[];
-  const int nap = dd.nap;
-  for (int q = threadIdx.x; q < nap; q += TB) xs[q] = dd.rr[q];
+  for (int q = threadIdx.x; q < nap; q += TB) xs[q] = x[q];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int row = blockIdx.x * 4 + wv; row < nap; row += gridDim.x * 4) {
-    const double2 *src = reinterpret_cast<const double2 *>(dd.S + (size_t)row * nap);
+    const double2 *src = reinterpret_cast<const double2 *>(Mx + (size_t)row * nap);
     const double2 *x2 = reinterpret_cast<const double2 *>(xs);
     double s0 = 0.0, s1 = 0.0;
     int q = lane;
-    for (; q + 7 * 64 < nap / 2; q += 8 * 64) {              // eight 16-byte loads in flight per lane
+    for (; q + 7 * 64 < nap / 2; q += 8 * 64) {
       double2 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = src[q + 64 * u];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const double2 x = x2[q + 64 * u]; s0 += v[u].x * x.x; s1 += v[u].y * x.y; }
+      for (int u = 0; u < 8; ++u) { const double2 xx = x2[q + 64 * u]; s0 += v[u].x * xx.x; s1 += v[u].y * xx.y; }
     }
-    for (; q < nap / 2; q += 64) { const double2 v = src[q], x = x2[q]; s0 += v.x * x.x; s1 += v.y * x.y; }
+    for (; q < nap / 2; q += 64) { const double2 v = src[q], xx = x2[q]; s0 += v.x * xx.x; s1 += v.y * xx.y; }
     const double s = wave_sum(s0 + s1);
-    if (lane == 0) dd.vv[row] = s;
+    if (lane == 0) y[row] = s;
   }
+}
+// Check of a fresh inverse: u = a fixed vector of +-(1 .. 2); after y = S^-1 u and z = S0 y (the matrix as formed), err = max |z - u|
+__device__ __forceinline__ double dd_probe_value(int a) { const unsigned h = (unsigned)a * 2654435761u; return ((h >> 9) & 1 ? -1.0 : 1.0) * (1.0 + (double)((h >> 12) & 1023) / 1024.0); }
+__global__ void __launch_bounds__(TB) k_dd_probe_fill(DdCtx dd) {
+  for (int a = blockIdx.x * TB + threadIdx.x; a < dd.nap; a += gridDim.x * TB) dd.rr[a] = a < dd.na ? dd_probe_value(a) : 0.0;
+}
+__global__ void __launch_bounds__(TB) k_dd_probe_err(DdCtx dd, const double *z, double *err) {
+  __shared__ double red[16];
+  double m = 0.0;
+  for (int a = threadIdx.x; a < dd.na; a += TB) { const double d = fabs(z[a] - dd_probe_value(a)); m = fmax(m, d == d ? d : 1e300); }
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *err = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 // x~ = x~0 + v on the unknowns of the reduced system (the engine's eliminated variables are k_admm_finalize's); solve complete
 __global__ void __launch_bounds__(TB) k_dd_finish(Ctx c, DdCtx dd) {
@@ -320,7 +335,6 @@ __global__ void __launch_bounds__(TB) k_dd_finish(Ctx c, DdCtx dd) {
     c.va[j] = c.vx[j] + v;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    st->iters[0] = 1; st->iters[1] = 0; st->done = 1;
-    if (*dd.flag) st->neg_curv = 1;
+    st->iters[0] = 1; st->iters[1] = 0; st->done = 1;      // (a pivot that was not positive never gets here: dd_refresh drops the inverse)
   }
 }

@@ -2598,6 +2598,7 @@ struct hipeng {
   int res_kind = 0;          // 0: launch-per-step only, 1: k_pcg_resident, 2: k_pcg_blockres, 3: block-direct solve (k_blk_apply / k_blk_finish), 4: dense-direct solve (dense_direct.h)
   BdCtx bd{};                // block-direct form (res_kind 3)
   DdCtx dd{};                // dense-direct form (res_kind 4)
+  double *dd_init_r = nullptr; int dd_init_stride = 4; double dd_check = 0.0;   // what dd_disable restores; the last inverse's check
   bool elim_rhs_dirty = false;   // q, the scaling, the matrices or the iterates changed since the m-part of the right-hand side was formed: with
                              // eliminated variables it carries their q_y and coefficients (elim_vb), so hipeng_run_admm forms it again first
   std::vector<double> h_rho; // host copy of rho (the capacitance matrix of the block-direct form needs the huge rows' entries)

@@ -138,3 +138,27 @@ def test_general_qps_forced_dense_match_oracle(gpu_lib, oracle_mod, seed):
     sg.update(Px=Pu.data); so.update(Px=Pu.data)                # new values of P: the dense matrix is formed again
     r1, r2 = sg.solve(), so.solve()
     assert r1.info.iter == r2.info.iter and _rel(r1.x, r2.x) < 1e-6 and _rel(r1.y, r2.y) < 1e-6
+
+
+def test_an_inverse_that_fails_its_check_is_dropped(gpu_lib, oracle_mod):
+    """The block sweeps are Gauss-Jordan in blocks: their error grows like cond^2 eps.  Every fresh inverse is checked against the
+    matrix as formed (dd_refresh); on a reduced matrix of condition 1e7 (eigenvalues of P from 1e-5 up, equality rows at 1e3 rho)
+    the check fails, the engine drops the dense solve at setup and the launch-per-step PCG solves the problem -- same answer as
+    the oracle, no false non-convexity report."""
+    import osqp_amd
+    rng = np.random.default_rng(4)
+    n, m = 200, 60
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    P = Q @ np.diag(10.0 ** rng.uniform(-5, 1, n)) @ Q.T
+    P = sparse.csc_matrix(0.5 * (P + P.T))
+    A = sparse.random(m, n, density=0.2, format="csc", random_state=rng)
+    x0 = rng.standard_normal(n); Ax = A @ x0
+    l = Ax - rng.uniform(0, 1, m); u = Ax + rng.uniform(0, 1, m)
+    l[:20] = u[:20] = Ax[:20]
+    pb = dict(P=sparse.triu(P, format="csc"), q=rng.standard_normal(n), A=A, l=l, u=u)
+    with _env(OSQP_AMD_DENSE_DIRECT=2, OSQP_AMD_RESIDENT=0):
+        sg = osqp_amd.OSQP().setup(**pb)
+    assert _info(sg)["form"] == 0                    # built, checked, dropped
+    rg, ro = sg.solve(), oracle_mod.OracleOSQP().setup(**pb).solve()
+    assert rg.info.status == ro.info.status == "solved" and rg.info.iter == ro.info.iter
+    assert _rel(rg.x, ro.x) < 1e-5 and _rel(rg.y, ro.y) < 1e-5
