@@ -37,7 +37,8 @@ struct DdCtx {
   const int *drow;          // [nd] row of A
   const char *isdense;      // [m] 1: the row is in R
   double *rr, *vv;          // [nap] reduced residual, solution
-  double *D, *Bp, *T;       // inversion: pivot block inverse [128][128], transposed column panel W' [128][nap], swept panel (W D)' [128][nap]
+  double *D, *Bp, *T;       // inversion: [128][128] scratch, two packed panels [128][nap]
+  double *Tp, *X2;          // Cholesky route: a transposed block row [nap][128], nap x nap scratch
   int *flag;                // [0] a pivot was not positive
 };
 
@@ -45,7 +46,7 @@ struct DdCtx {
 // contiguous doubles per wave load), B: [K][ldb], C: [M][ldc].  Workgroup = 128 x 128 of C, wavefront = 64 x 64 = 4 x 4 tiles.
 // Tiles whose rows lie in [sr0, sr1) or columns in [sc0, sc1) are left alone (the pivot block row / column of a sweep step).
 __global__ void __launch_bounds__(TB, 2) k_dd_gemm_tn(double *C, int ldc, const double *T, int ldt, const double *B, int ldb, const double *w,
-                                                   int M, int N, int K, double alpha, double beta, int sr0, int sr1, int sc0, int sc1, int lower) {
+                                                   int M, int N, int K, double alpha, double beta, int sr0, int sr1, int sc0, int sc1, int lower, int kmode) {
   const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;      // (tried: an XCD-contiguous workgroup -> tile map; 24.9 -> 23.9 TFLOP/s, the sweep 21.6 -> 26.9 ms)
   if ((row0 >= sr0 && row0 < sr1) || (col0 >= sc0 && col0 < sc1)) return;
   if (lower && col0 > row0) return;            // symmetric result: the tiles on and below the diagonal only (k_dd_mirror fills the rest)
@@ -72,8 +73,10 @@ __global__ void __launch_bounds__(TB, 2) k_dd_gemm_tn(double *C, int ldc, const 
       }
     }
   };
-  load(0, a, b);
-  for (int k0 = 0; k0 < K; k0 += 4 * DD_CH) {
+  // kmode 1: B is lower triangular (B[k][j] = 0 for k < j): k starts at the column tile; 2: T and B both are: k starts at the row tile
+  const int kbeg = kmode == 1 ? col0 : (kmode == 2 ? row0 : 0);
+  load(kbeg, a, b);
+  for (int k0 = kbeg; k0 < K; k0 += 4 * DD_CH) {
     if (k0 + 4 * DD_CH < K) load(k0 + 4 * DD_CH, an, bn);
 #pragma unroll
     for (int s = 0; s < DD_CH; ++s)
@@ -185,7 +188,7 @@ __global__ void __launch_bounds__(TB) k_dd_mirror(double *A, int n, int neg) {
 //   D = A_kk^-1 (LDS);  W = column panel k (packed transposed, Wt);  V = W D (Vt = D Wt: one 128 x n GEMM);
 //   A_ij -= V_i W_j' for the lower tiles outside block row / column k (one GEMM);  panel <- V;  A_kk <- -D.
 // All pivots swept: A = -(A^-1); mirrored and negated at the end.
-static int dd_invert(hipStream_t stream, double *A, int n, double *D, double *Wt, double *Vt, int *flag) {
+static int dd_invert_sweep(hipStream_t stream, double *A, int n, double *D, double *Wt, double *Vt, int *flag) {
   static bool lds_set = false;
   if (!lds_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dd_pivot), hipFuncAttributeMaxDynamicSharedMemorySize, DD_NB * DD_NB * (int)sizeof(double)) != hipSuccess) return HIPENG_ERR_HIP;
@@ -198,13 +201,142 @@ static int dd_invert(hipStream_t stream, double *A, int n, double *D, double *Wt
     hipLaunchKernelGGL(k_dd_panel, dim3(n / 64), dim3(TB), 0, stream, (const double *)A, n, n, kb, Wt);
     // Vt[c][i] = sum_r D[r][c] Wt[r][i]  (D symmetric)
     hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nb, 1), dim3(TB), 0, stream, Vt, n, (const double *)D, DD_NB, (const double *)Wt, n, (const double *)nullptr,
-                       DD_NB, n, DD_NB, 1.0, 0.0, -1, -1, p0, p1, 0);
+                       DD_NB, n, DD_NB, 1.0, 0.0, -1, -1, p0, p1, 0, 0);
     // A[i][j] -= sum_c Vt[c][i] Wt[c][j]
     hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nb, nb), dim3(TB), 0, stream, A, n, (const double *)Vt, n, (const double *)Wt, n, (const double *)nullptr,
-                       n, n, DD_NB, -1.0, 1.0, p0, p1, p0, p1, 1);
+                       n, n, DD_NB, -1.0, 1.0, p0, p1, p0, p1, 1, 0);
     hipLaunchKernelGGL(k_dd_store_panel, dim3(n / 64), dim3(TB), 0, stream, A, n, n, kb, (const double *)Vt, (const double *)D);
   }
   hipLaunchKernelGGL(k_dd_mirror, dim3(n / 64, n / 64), dim3(TB), 0, stream, A, n, 1);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- the same inverse by blocked Cholesky: A = L L',  X = L^-1 (blocked triangular inversion),  A^-1 = X' X -----------------------------
+// Error cond(A) eps where the sweeps above have cond(A)^2 eps (tools/dd_illcond.py); the same n^3 flops, all but the 128 x 128 diagonal
+// work in k_dd_gemm_tn.  Nothing is ever multiplied by an explicit inverse of a diagonal block: panels are SOLVED against it.
+//
+// L_kk = chol(A_kk) in LDS (lower; the upper triangle of the block is zeroed): 1024 threads, column p scaled, trailing rank-one update
+__global__ void __launch_bounds__(INV_TB) k_dd_chol(double *A, int lda, int kb, int *flag) {
+  extern __shared__ __attribute__((aligned(16))) double bl[];       // 128 x 128
+  __shared__ double colp[DD_NB];
+  constexpr int RS = INV_TB / DD_NB, RU = DD_NB / RS;
+  const int t = threadIdx.x, j = t & (DD_NB - 1), i0 = t / DD_NB;
+  double *blk = A + (size_t)kb * DD_NB * lda + (size_t)kb * DD_NB;
+  for (int i = i0; i < DD_NB; i += RS) bl[i * DD_NB + j] = blk[(size_t)i * lda + j];
+  __syncthreads();
+  for (int p = 0; p < DD_NB; ++p) {
+    const double d = bl[p * DD_NB + p];
+    if (!(d > 0.0) && t == 0) atomicOr(flag, 1);
+    const double inv = 1.0 / sqrt(d > 0.0 ? d : 1.0);
+    __syncthreads();
+    if (t < DD_NB) { const double v = t >= p ? bl[t * DD_NB + p] * inv : 0.0; colp[t] = v; bl[t * DD_NB + p] = v; }      // column p of L (l_pp = sqrt(d))
+    __syncthreads();
+    if (j > p) {
+      const double lj = colp[j];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) { const int i = i0 + RS * u; if (i >= j) bl[i * DD_NB + j] -= colp[i] * lj; }
+    }
+    __syncthreads();
+  }
+  for (int i = i0; i < DD_NB; i += RS) blk[(size_t)i * lda + j] = j <= i ? bl[i * DD_NB + j] : 0.0;
+}
+// Solve L_kk z = v for `cnt` vectors stored packed as V[c][v0 + q] (component c = 0..127 of vector q), in place: one thread per vector,
+// the vector in LDS (its own column: no bank conflict), L_kk packed lower in LDS (its entries are read by all lanes at once: broadcast).
+// z_c = (v_c - sum_{t<c} L[c][t] z_t) / L[c][c].  Serves the Cholesky panel (Z_i = W_i L^-T: every row of the panel is a vector), the
+// block rows of the triangular inverse (X = L_ii^-1 Y: every column is one) and the diagonal blocks (vectors = the identity).
+__global__ void __launch_bounds__(64) k_dd_trsm(const double *A, int lda, int kb, double *V, int ldv, int v0, int cnt) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *Lp = sm, *ws = sm + DD_NB * (DD_NB + 1) / 2;                  // Lp[c (c + 1) / 2 + t], ws[c][64]
+  const double *blk = A + (size_t)kb * DD_NB * lda + (size_t)kb * DD_NB;
+  for (int q = threadIdx.x; q < DD_NB * DD_NB; q += 64) { const int c = q / DD_NB, t = q % DD_NB; if (t <= c) Lp[c * (c + 1) / 2 + t] = blk[(size_t)c * lda + t]; }
+  const int qv = blockIdx.x * 64 + threadIdx.x;
+  const bool on = qv < cnt;
+  double *col = V + v0 + qv;
+  for (int c = 0; c < DD_NB; ++c) ws[c * 64 + threadIdx.x] = on ? col[(size_t)c * ldv] : 0.0;
+  __syncthreads();
+  for (int c = 0; c < DD_NB; ++c) {
+    const double *Lr = Lp + c * (c + 1) / 2;
+    double s0 = ws[c * 64 + threadIdx.x], s1 = 0.0;
+    int t2 = 0;
+    for (; t2 + 1 < c; t2 += 2) { s0 -= Lr[t2] * ws[t2 * 64 + threadIdx.x]; s1 -= Lr[t2 + 1] * ws[(t2 + 1) * 64 + threadIdx.x]; }
+    if (t2 < c) s0 -= Lr[t2] * ws[t2 * 64 + threadIdx.x];
+    ws[c * 64 + threadIdx.x] = (s0 + s1) / Lr[c];
+  }
+  if (on) for (int c = 0; c < DD_NB; ++c) col[(size_t)c * ldv] = ws[c * 64 + threadIdx.x];
+}
+// mode 0: A[i][p0 + c] = V[c][i] for the rows i >= p1 (the Cholesky panel back into the matrix);
+// mode 1: A[p0 + r][j] = -V[r][j] for the columns j < p0 (a block row of the triangular inverse);
+// mode 2: A_kk = V[r][c] (its diagonal block);  mode 3: V = the 128 x 128 identity
+__global__ void __launch_bounds__(TB) k_dd_put(double *A, int lda, int n, int kb, double *V, int ldv, int mode) {
+  __shared__ double tile[DD_NB][64 + 1];
+  const int i0 = blockIdx.x * 64, p0 = kb * DD_NB, p1 = p0 + DD_NB;
+  if (mode == 0) {
+    if (i0 < p1) return;
+    for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) { const int r = q / 64, i = q % 64; tile[r][i] = i0 + i < n ? V[(size_t)r * ldv + i0 + i] : 0.0; }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) { const int i = q / DD_NB, r = q % DD_NB; if (i0 + i < n) A[(size_t)(i0 + i) * lda + p0 + r] = tile[r][i]; }
+  } else if (mode == 1) {
+    if (i0 >= p0) return;
+    for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) { const int r = q / 64, i = q % 64; A[(size_t)(p0 + r) * lda + i0 + i] = -V[(size_t)r * ldv + i0 + i]; }
+  } else if (mode == 2) {
+    for (int q = blockIdx.x * TB + threadIdx.x; q < DD_NB * DD_NB; q += gridDim.x * TB) A[(size_t)(p0 + q / DD_NB) * lda + p0 + q % DD_NB] = V[(size_t)(q / DD_NB) * ldv + q % DD_NB];
+  } else {
+    for (int q = blockIdx.x * TB + threadIdx.x; q < DD_NB * DD_NB; q += gridDim.x * TB) V[(size_t)(q / DD_NB) * ldv + q % DD_NB] = (q / DD_NB == q % DD_NB) ? 1.0 : 0.0;
+  }
+}
+// Tp[k][r] = A[p0 + r][k] for k < p0: block row kb of L transposed ([p0][128]), the T operand of  Y = L_i,0:i X_0:i,0:i
+__global__ void __launch_bounds__(TB) k_dd_rowT(const double *A, int lda, int kb, double *Tp) {
+  __shared__ double tile[DD_NB][64 + 1];
+  const int k0 = blockIdx.x * 64, p0 = kb * DD_NB;
+  if (k0 >= p0) return;
+  for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) { const int r = q / 64, k = q % 64; tile[r][k] = A[(size_t)(p0 + r) * lda + k0 + k]; }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 64 * DD_NB; q += TB) { const int k = q / DD_NB, r = q % DD_NB; Tp[(size_t)(k0 + k) * DD_NB + r] = tile[r][k]; }
+}
+
+// A (n x n, n a multiple of 128, symmetric positive definite, lower tiles valid) <- A^-1 (both triangles) on `stream`.
+// Wt, Yt: [128][n] panels; Tp: [n][128]; X2: n x n scratch.
+static int dd_invert_chol(hipStream_t stream, double *A, int n, double *Wt, double *Yt, double *Tp, double *X2, int *flag) {
+  static bool lds_set = false;
+  const size_t trsm_lds = ((size_t)DD_NB * (DD_NB + 1) / 2 + (size_t)DD_NB * 64) * sizeof(double);
+  if (!lds_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dd_chol), hipFuncAttributeMaxDynamicSharedMemorySize, DD_NB * DD_NB * (int)sizeof(double)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_dd_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsm_lds) != hipSuccess) return HIPENG_ERR_HIP;
+    lds_set = true;
+  }
+  const int nb = n / DD_NB;
+  const double *nul = nullptr;
+  // (a) A = L L': per block column the diagonal factor, the panel solved against it, the trailing lower tiles updated
+  for (int kb = 0; kb < nb; kb++) {
+    const int p1 = (kb + 1) * DD_NB;
+    hipLaunchKernelGGL(k_dd_chol, dim3(1), dim3(INV_TB), DD_NB * DD_NB * sizeof(double), stream, A, n, kb, flag);
+    if (p1 >= n) break;
+    hipLaunchKernelGGL(k_dd_panel, dim3(n / 64), dim3(TB), 0, stream, (const double *)A, n, n, kb, Wt);            // Wt[c][i] = A[i][p0 + c]  (rows i >= p0 are used)
+    hipLaunchKernelGGL(k_dd_trsm, dim3((n - p1 + 63) / 64), dim3(64), trsm_lds, stream, (const double *)A, n, kb, Wt, n, p1, n - p1);
+    hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nb, nb), dim3(TB), 0, stream, A, n, (const double *)Wt, n, (const double *)Wt, n, nul,
+                       n, n, DD_NB, -1.0, 1.0, 0, p1, 0, p1, 1, 0);
+    hipLaunchKernelGGL(k_dd_put, dim3(n / 64), dim3(TB), 0, stream, A, n, n, kb, Wt, n, 0);
+  }
+  // (b) X = L^-1 in place, block row by block row:  X_i,0:i = -L_ii^-1 (L_i,0:i X_0:i,0:i),  X_ii = L_ii^-1
+  for (int kb = 0; kb < nb; kb++) {
+    const int p0 = kb * DD_NB;
+    if (kb > 0) {
+      hipLaunchKernelGGL(k_dd_rowT, dim3(n / 64), dim3(TB), 0, stream, (const double *)A, n, kb, Tp);
+      hipLaunchKernelGGL(k_dd_gemm_tn, dim3(kb, 1), dim3(TB), 0, stream, Yt, n, (const double *)Tp, DD_NB, (const double *)A, n, nul,
+                         DD_NB, p0, p0, 1.0, 0.0, -1, -1, -1, -1, 0, 1);
+      hipLaunchKernelGGL(k_dd_trsm, dim3((p0 + 63) / 64), dim3(64), trsm_lds, stream, (const double *)A, n, kb, Yt, n, 0, p0);
+    }
+    hipLaunchKernelGGL(k_dd_put, dim3(16), dim3(TB), 0, stream, A, n, n, kb, Wt, n, 3);                            // Wt[0:128][0:128] = I
+    hipLaunchKernelGGL(k_dd_trsm, dim3(2), dim3(64), trsm_lds, stream, (const double *)A, n, kb, Wt, n, 0, DD_NB);
+    if (kb > 0) hipLaunchKernelGGL(k_dd_put, dim3(n / 64), dim3(TB), 0, stream, A, n, n, kb, Yt, n, 1);
+    hipLaunchKernelGGL(k_dd_put, dim3(16), dim3(TB), 0, stream, A, n, n, kb, Wt, n, 2);
+  }
+  // (c) A^-1 = X' X on the lower tiles (k from the row tile on: X is lower triangular), then both triangles
+  hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nb, nb), dim3(TB), 0, stream, X2, n, (const double *)A, n, (const double *)A, n, nul,
+                     n, n, n, 1.0, 0.0, -1, -1, -1, -1, 1, 2);
+  HIPCHK(hipMemcpyAsync(A, X2, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(k_dd_mirror, dim3(n / 64, n / 64), dim3(TB), 0, stream, A, n, 0);
   HIPCHK(hipGetLastError());
   return 0;
 }

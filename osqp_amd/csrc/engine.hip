@@ -2598,7 +2598,7 @@ struct hipeng {
   int res_kind = 0;          // 0: launch-per-step only, 1: k_pcg_resident, 2: k_pcg_blockres, 3: block-direct solve (k_blk_apply / k_blk_finish), 4: dense-direct solve (dense_direct.h)
   BdCtx bd{};                // block-direct form (res_kind 3)
   DdCtx dd{};                // dense-direct form (res_kind 4)
-  double *dd_init_r = nullptr; int dd_init_stride = 4; double dd_check = 0.0;   // what dd_disable restores; the last inverse's check
+  double *dd_init_r = nullptr; int dd_init_stride = 4; double dd_check = 0.0; bool dd_chol = false;   // what dd_disable restores; the last inverse's check; the Cholesky route was needed
   bool elim_rhs_dirty = false;   // q, the scaling, the matrices or the iterates changed since the m-part of the right-hand side was formed: with
                              // eliminated variables it carries their q_y and coefficients (elim_vb), so hipeng_run_admm forms it again first
   std::vector<double> h_rho; // host copy of rho (the capacitance matrix of the block-direct form needs the huge rows' entries)
@@ -4334,7 +4334,7 @@ extern "C" int hipeng_resident_info(hipeng *e, long long out[16]) {
   out[12] = std::max<long long>(e->res_slow_max, s.res_slow_max); out[13] = e->res_repub + s.res_repub; out[14] = e->res_fails; out[15] = e->res_kind == 3 ? e->bd.kc : 0;
   if (e->res_kind == 2) { out[2] = 64; out[3] = e->bc.nwg; out[4] = 0; out[5] = 0; }
   if (e->res_kind == 3) { out[2] = 0; out[3] = e->c.dP.nblk; out[4] = 0; out[5] = 0; }
-  if (e->res_kind == 4) { out[2] = 0; out[3] = e->dd.na; out[4] = (long long)e->dd.nap * e->dd.nap; out[5] = 0; out[15] = e->dd.nb2; }
+  if (e->res_kind == 4) { out[2] = 0; out[3] = e->dd.na; out[4] = (long long)e->dd.nap * e->dd.nap; out[5] = e->dd_chol ? 1 : 0; out[15] = e->dd.nb2; }
   return 0;
 }
 

@@ -35,7 +35,7 @@ def _info(solver):
     L.hipeng_resident_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     out = (C.c_longlong * 16)()
     assert L.hipeng_resident_info(solver.engine(), out) == 0
-    return dict(built=out[0], in_use=out[1], dense_unknowns=out[3], form=out[9], sparse_unknowns=out[15])
+    return dict(built=out[0], in_use=out[1], dense_unknowns=out[3], cholesky=out[5], form=out[9], sparse_unknowns=out[15])
 
 
 def _rel(a, b):
@@ -140,11 +140,11 @@ def test_general_qps_forced_dense_match_oracle(gpu_lib, oracle_mod, seed):
     assert r1.info.iter == r2.info.iter and _rel(r1.x, r2.x) < 1e-6 and _rel(r1.y, r2.y) < 1e-6
 
 
-def test_an_inverse_that_fails_its_check_is_dropped(gpu_lib, oracle_mod):
+def test_an_inverse_that_fails_its_check_is_computed_again_by_cholesky(gpu_lib, oracle_mod):
     """The block sweeps are Gauss-Jordan in blocks: their error grows like cond^2 eps.  Every fresh inverse is checked against the
     matrix as formed (dd_refresh); on a reduced matrix of condition 1e7 (eigenvalues of P from 1e-5 up, equality rows at 1e3 rho)
-    the check fails, the engine drops the dense solve at setup and the launch-per-step PCG solves the problem -- same answer as
-    the oracle, no false non-convexity report."""
+    the sweeps' inverse fails the check and the blocked Cholesky route (cond eps) takes over: the engine keeps the dense solve, no
+    false non-convexity report, same trajectory as the oracle."""
     import osqp_amd
     rng = np.random.default_rng(4)
     n, m = 200, 60
@@ -158,7 +158,28 @@ def test_an_inverse_that_fails_its_check_is_dropped(gpu_lib, oracle_mod):
     pb = dict(P=sparse.triu(P, format="csc"), q=rng.standard_normal(n), A=A, l=l, u=u)
     with _env(OSQP_AMD_DENSE_DIRECT=2, OSQP_AMD_RESIDENT=0):
         sg = osqp_amd.OSQP().setup(**pb)
-    assert _info(sg)["form"] == 0                    # built, checked, dropped
+    inf = _info(sg)
+    assert inf["form"] == 4 and inf["cholesky"] == 1, inf
     rg, ro = sg.solve(), oracle_mod.OracleOSQP().setup(**pb).solve()
     assert rg.info.status == ro.info.status == "solved" and rg.info.iter == ro.info.iter
-    assert _rel(rg.x, ro.x) < 1e-5 and _rel(rg.y, ro.y) < 1e-5
+    assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
+    assert _info(sg)["form"] == 4
+
+
+def test_blocked_cholesky_inversion_on_ill_conditioned_matrices(gpu_lib):
+    """hipeng_dense_invert_selftest with OSQP_AMD_DENSE_CHOL=1: eigenvalues from 1e-6 to 1e3; |A^-1 A - I| within a small multiple
+    of numpy's own (the block sweeps are off by 2.4 on this matrix)."""
+    import osqp_amd
+    f = osqp_amd.lib().hipeng_dense_invert_selftest
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(4)
+    n = 512
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A = Q @ np.diag(10.0 ** rng.uniform(-6, 3, n)) @ Q.T
+    A = 0.5 * (A + A.T)
+    Ainv = np.zeros((n, n))
+    with _env(OSQP_AMD_DENSE_CHOL=1):
+        assert f(n, A.ctypes.data_as(C.c_void_p), Ainv.ctypes.data_as(C.c_void_p), None) == 0
+    ref = np.abs(np.linalg.inv(A) @ A - np.eye(n)).max()
+    assert np.abs(Ainv @ A - np.eye(n)).max() <= 10 * ref + 1e-10
