@@ -46,7 +46,8 @@ struct DdCtx {
 // contiguous doubles per wave load), B: [K][ldb], C: [M][ldc].  Workgroup = 128 x 128 of C, wavefront = 64 x 64 = 4 x 4 tiles.
 // Tiles whose rows lie in [sr0, sr1) or columns in [sc0, sc1) are left alone (the pivot block row / column of a sweep step).
 __global__ void __launch_bounds__(TB, 2) k_dd_gemm_tn(double *C, int ldc, const double *T, int ldt, const double *B, int ldb, const double *w,
-                                                   int M, int N, int K, double alpha, double beta, int sr0, int sr1, int sc0, int sc1, int lower, int kmode) {
+                                                   int M, int N, int K, double alpha, double beta, int sr0, int sr1, int sc0, int sc1, int lower, int kmode,
+                                                   int ksl = 0, long long cz = 0) {
   const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;      // (tried: an XCD-contiguous workgroup -> tile map; 24.9 -> 23.9 TFLOP/s, the sweep 21.6 -> 26.9 ms)
   if ((row0 >= sr0 && row0 < sr1) || (col0 >= sc0 && col0 < sc1)) return;
   if (lower && col0 > row0) return;            // symmetric result: the tiles on and below the diagonal only (k_dd_mirror fills the rest)
@@ -74,7 +75,10 @@ __global__ void __launch_bounds__(TB, 2) k_dd_gemm_tn(double *C, int ldc, const 
     }
   };
   // kmode 1: B is lower triangular (B[k][j] = 0 for k < j): k starts at the column tile; 2: T and B both are: k starts at the row tile
-  const int kbeg = kmode == 1 ? col0 : (kmode == 2 ? row0 : 0);
+  // ksl > 0: split K -- slice blockIdx.z takes k in [z ksl, (z + 1) ksl) and writes its partial product to C + z cz (summed in a fixed
+  // order afterwards, k_dd_sum_slices): skinny products (128 rows, k up to n) fill the machine that way
+  int kbeg = kmode == 1 ? col0 : (kmode == 2 ? row0 : 0);
+  if (ksl > 0) { kbeg = max(kbeg, (int)blockIdx.z * ksl); K = min(K, ((int)blockIdx.z + 1) * ksl); C += (size_t)blockIdx.z * cz; }
   load(kbeg, a, b);
   for (int k0 = kbeg; k0 < K; k0 += 4 * DD_CH) {
     if (k0 + 4 * DD_CH < K) load(k0 + 4 * DD_CH, an, bn);
@@ -249,11 +253,24 @@ __global__ void __launch_bounds__(64) k_dd_trsm(const double *A, int lda, int kb
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *Lp = sm, *ws = sm + DD_NB * (DD_NB + 1) / 2;                  // Lp[c (c + 1) / 2 + t], ws[c][64]
   const double *blk = A + (size_t)kb * DD_NB * lda + (size_t)kb * DD_NB;
-  for (int q = threadIdx.x; q < DD_NB * DD_NB; q += 64) { const int c = q / DD_NB, t = q % DD_NB; if (t <= c) Lp[c * (c + 1) / 2 + t] = blk[(size_t)c * lda + t]; }
+  // (sixteen loads in flight per lane: one at a time these two loops were 270 of the kernel's 364 us)
+  for (int q0 = threadIdx.x; q0 < DD_NB * DD_NB; q0 += 64 * 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int q = q0 + 64 * u, c = q / DD_NB, t = q % DD_NB; v[u] = t <= c ? blk[(size_t)c * lda + t] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int q = q0 + 64 * u, c = q / DD_NB, t = q % DD_NB; if (t <= c) Lp[c * (c + 1) / 2 + t] = v[u]; }
+  }
   const int qv = blockIdx.x * 64 + threadIdx.x;
   const bool on = qv < cnt;
   double *col = V + v0 + qv;
-  for (int c = 0; c < DD_NB; ++c) ws[c * 64 + threadIdx.x] = on ? col[(size_t)c * ldv] : 0.0;
+  for (int c0 = 0; c0 < DD_NB; c0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = on ? col[(size_t)(c0 + u) * ldv] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) ws[(c0 + u) * 64 + threadIdx.x] = v[u];
+  }
   __syncthreads();
   for (int c = 0; c < DD_NB; ++c) {
     const double *Lr = Lp + c * (c + 1) / 2;
@@ -283,6 +300,15 @@ __global__ void __launch_bounds__(TB) k_dd_put(double *A, int lda, int n, int kb
     for (int q = blockIdx.x * TB + threadIdx.x; q < DD_NB * DD_NB; q += gridDim.x * TB) A[(size_t)(p0 + q / DD_NB) * lda + p0 + q % DD_NB] = V[(size_t)(q / DD_NB) * ldv + q % DD_NB];
   } else {
     for (int q = blockIdx.x * TB + threadIdx.x; q < DD_NB * DD_NB; q += gridDim.x * TB) V[(size_t)(q / DD_NB) * ldv + q % DD_NB] = (q / DD_NB == q % DD_NB) ? 1.0 : 0.0;
+  }
+}
+// Y[r][j] = sum over the K slices of part[z][r][j] (fixed order), r < 128, j < cols
+__global__ void __launch_bounds__(TB) k_dd_sum_slices(double *Y, int ldy, const double *part, long long cz, int nz, int cols) {
+  for (long long q = (long long)blockIdx.x * TB + threadIdx.x; q < (long long)DD_NB * cols; q += (long long)gridDim.x * TB) {
+    const int r = (int)(q / cols), j = (int)(q % cols);
+    double s = 0.0;
+    for (int z = 0; z < nz; ++z) s += part[(size_t)z * cz + (size_t)r * ldy + j];
+    Y[(size_t)r * ldy + j] = s;
   }
 }
 // Tp[k][r] = A[p0 + r][k] for k < p0: block row kb of L transposed ([p0][128]), the T operand of  Y = L_i,0:i X_0:i,0:i
@@ -323,8 +349,11 @@ static int dd_invert_chol(hipStream_t stream, double *A, int n, double *Wt, doub
     const int p0 = kb * DD_NB;
     if (kb > 0) {
       hipLaunchKernelGGL(k_dd_rowT, dim3(n / 64), dim3(TB), 0, stream, (const double *)A, n, kb, Tp);
-      hipLaunchKernelGGL(k_dd_gemm_tn, dim3(kb, 1), dim3(TB), 0, stream, Yt, n, (const double *)Tp, DD_NB, (const double *)A, n, nul,
-                         DD_NB, p0, p0, 1.0, 0.0, -1, -1, -1, -1, 0, 1);
+      // 128 rows x p0 columns, k up to p0: on kb workgroups alone this was 1 ms per block row; k is split into slices of 512
+      const int nz = (p0 + 511) / 512;
+      hipLaunchKernelGGL(k_dd_gemm_tn, dim3(kb, 1, nz), dim3(TB), 0, stream, X2, n, (const double *)Tp, DD_NB, (const double *)A, n, nul,
+                         DD_NB, p0, p0, 1.0, 0.0, -1, -1, -1, -1, 0, 1, 512, (long long)DD_NB * n);
+      hipLaunchKernelGGL(k_dd_sum_slices, dim3(std::min(1024, (DD_NB * p0 + TB - 1) / TB)), dim3(TB), 0, stream, Yt, n, (const double *)X2, (long long)DD_NB * n, nz, p0);
       hipLaunchKernelGGL(k_dd_trsm, dim3((p0 + 63) / 64), dim3(64), trsm_lds, stream, (const double *)A, n, kb, Yt, n, 0, p0);
     }
     hipLaunchKernelGGL(k_dd_put, dim3(16), dim3(TB), 0, stream, A, n, n, kb, Wt, n, 3);                            // Wt[0:128][0:128] = I
