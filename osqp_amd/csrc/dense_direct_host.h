@@ -81,23 +81,13 @@ static int build_dense_direct(hipeng *e, const csc *P, const csc *A) {
     return 0;
   }
   e->dd = dd;
-  e->dd_init_r = e->c.init_r; e->dd_init_stride = e->c.init_stride;       // (what the launch-per-step kernels use: dd_disable puts them back)
+  e->dd_init_r = e->c.init_r; e->dd_init_stride = e->c.init_stride;       // (what the launch-per-step kernels use: direct_disable puts them back)
   e->c.init_r = e->c.r; e->c.init_stride = 1;
   e->c.fin_wave_rows = 1;
   e->res_kind = 4; e->res_on = e->res_use = true;
   if (e->trace) fprintf(stderr, "[osqp_amd] dense-direct solve: %d dense unknowns (%d x %d inverse, %.0f MB), %d sparse unknowns by Schur complement, %d dense rows of A\n",
                         na, nap, nap, 8e-6 * nap * nap, nb2, nd);
   return 0;
-}
-
-// The inverse could not be trusted (see dd_refresh): this engine goes on with the launch-per-step PCG kernels for good.
-static void dd_disable(hipeng *e, const char *why, double err) {
-  if (e->trace) fprintf(stderr, "[osqp_amd] dense-direct solve dropped (%s, check %.2e): the PCG kernels take over\n", why, err);
-  for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.second);      // (they hold the Ctx by value)
-  e->graphs.clear();
-  e->c.init_r = e->dd_init_r; e->c.init_stride = e->dd_init_stride; e->c.fin_wave_rows = 0;
-  e->res_kind = 0; e->res_on = e->res_use = false;
-  e->calibrated = false; e->spec_lo = 0; e->start_dirty = true;
 }
 
 // New rho, sigma or matrix values: form the Schur complement again, invert it, and check the inverse against the matrix as formed.
@@ -154,7 +144,7 @@ static int dd_refresh(hipeng *e) {
   }
   e->dd_chol = attempt >= 1;                // (the inverse in use came from the Cholesky route)
   e->dd_check = err;
-  if (flag || !(err <= DD_CHECK)) dd_disable(e, flag ? "a pivot was not positive" : "the inverse failed its check", err);
+  if (flag || !(err <= DD_CHECK)) direct_disable(e, "dense-direct", flag ? "a pivot was not positive" : "the inverse failed its check", err);
   return 0;
 }
 

@@ -1871,6 +1871,8 @@ struct BdCtx {
   double *cinv;            // [nh][nh] (R_h^-1 + A_h W)^-1
   double *part;            // [MAX_HUGE_FOLD][nblk] partials of A_h t per block
   int    *flag;            // [0] a pivot was not positive
+  double *chk;             // [2] checks of a fresh inverse (bit patterns of non-negative doubles, atomicMax): blocks, capacitance matrix
+  double *cap0;            // [kc][kc] the capacitance matrix as formed (coupled form): its inverse is checked against it
   int     fin_dots;        // the kernel that writes x~ also leaves the folded huge rows' partials of A x~ for k_admm_finalize (no k_huge_dot launch)
   // coupled form (kc > 0): EVERY row of A with two or more entries -- sector rows, the budget row, whatever their length -- is a
   // term of the low-rank part; nothing of W is stored (see k_cpl_dot)
@@ -2155,6 +2157,57 @@ __global__ void __launch_bounds__(TB) k_cap_step(BdCtx bd, const double *src, do
 }
 
 #include "dense_direct.h"
+
+// Checks of the block-direct solve's fresh inverses (blk_refresh), as the dense-direct solve has them: k_blk_invert and the
+// capacitance steps are Gauss-Jordan (error ~ cond^2 eps).  Per block: u = probe values, y = Binv_b u, z = B_b y with B_b = P_b +
+// diag as k_blk_invert forms it; chk[0] = max |z - u| over all blocks.
+__global__ void __launch_bounds__(TB) k_blk_check(Ctx c, BdCtx bd) {
+  __shared__ double scratch[5 * DENSE_MAX];
+  __shared__ double red[16];
+  const double sigma = c.prm->sigma;
+  const DenseP inv{c.dP.nblk, c.dP.blk, bd.binv};
+  double worst = 0.0;
+  for (int db = blockIdx.x; db < c.dP.nblk; db += gridDim.x) {
+    const DenseBlk d = c.dP.blk[db];
+    const double y = dense_block_mv_x(inv, d, [](int j) { return dd_probe_value(j); }, scratch);
+    const int j = d.c0 + threadIdx.x;
+    const bool on = (int)threadIdx.x < d.b;
+    if (on) bd.t[j] = y;
+    __syncthreads();
+    double z = dense_block_mv_x(c.dP, d, [&](int jj) { return bd.t[jj]; }, scratch);
+    if (on) {
+      double dadd = sigma;
+      for (int k = c.Mk.rowptr[j]; k < c.Mk.rowptr[j + 1]; ++k) {
+        const int row = c.Mk.col[k] - c.n;
+        if (bd.kc && bd.cidx[row] >= 0) continue;
+        const double a = c.Mk.val[k]; dadd += c.rho[row] * a * a;
+      }
+      z += dadd * y;
+      const double e = fabs(z - dd_probe_value(j));
+      worst = fmax(worst, e == e ? e : 1e300);
+    }
+    __syncthreads();
+  }
+  for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = worst;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long *>(bd.chk), (unsigned long long)__double_as_longlong(fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))));
+}
+// coupled form: w = cap u, z = cap0 w (cap0: the capacitance matrix as formed, cap: its inverse); chk[1] = max |z - u|.  One workgroup.
+__global__ void __launch_bounds__(TB) k_cap_check(BdCtx bd) {
+  __shared__ double u[CPL_MAX], w[CPL_MAX], red[16];
+  const int kc = bd.kc;
+  for (int r = threadIdx.x; r < kc; r += TB) u[r] = dd_probe_value(r);
+  __syncthreads();
+  for (int r = threadIdx.x; r < kc; r += TB) { double s = 0.0; for (int q = 0; q < kc; ++q) s += bd.cap[(size_t)r * kc + q] * u[q]; w[r] = s; }
+  __syncthreads();
+  double worst = 0.0;
+  for (int r = threadIdx.x; r < kc; r += TB) { double s = 0.0; for (int q = 0; q < kc; ++q) s += bd.cap0[(size_t)r * kc + q] * w[q]; const double e = fabs(s - u[r]); worst = fmax(worst, e == e ? e : 1e300); }
+  for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = worst;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long *>(bd.chk + 1), (unsigned long long)__double_as_longlong(fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))));
+}
 
 // ---------------------------------------------------------------------------
 // Elimination of slack-like variables from the linear system (launch-per-step kernels and the resident PCG).
@@ -2598,7 +2651,7 @@ struct hipeng {
   int res_kind = 0;          // 0: launch-per-step only, 1: k_pcg_resident, 2: k_pcg_blockres, 3: block-direct solve (k_blk_apply / k_blk_finish), 4: dense-direct solve (dense_direct.h)
   BdCtx bd{};                // block-direct form (res_kind 3)
   DdCtx dd{};                // dense-direct form (res_kind 4)
-  double *dd_init_r = nullptr; int dd_init_stride = 4; double dd_check = 0.0; bool dd_chol = false;   // what dd_disable restores; the last inverse's check; the Cholesky route was needed
+  double *dd_init_r = nullptr; int dd_init_stride = 4; double dd_check = 0.0; bool dd_chol = false;   // what direct_disable restores; the last inverse's check; the Cholesky route was needed
   bool elim_rhs_dirty = false;   // q, the scaling, the matrices or the iterates changed since the m-part of the right-hand side was formed: with
                              // eliminated variables it carries their q_y and coefficients (elim_vb), so hipeng_run_admm forms it again first
   std::vector<double> h_rho; // host copy of rho (the capacitance matrix of the block-direct form needs the huge rows' entries)
@@ -3237,7 +3290,7 @@ static int build_blockdirect(hipeng *e) {
     std::vector<int> cidx((size_t)std::max(1, e->m), -1);
     for (size_t r = 0; r < kc; r++) cidx[crows[r]] = (int)r;
     if (dev_alloc(e, &d_crow, kc) || dev_alloc(e, &d_chuge, kc) || dev_alloc(e, &d_cidx, cidx.size()) || dev_alloc(e, &bd.cs, kc) || dev_alloc(e, &bd.cc, kc) ||
-        dev_alloc(e, &bd.cap, kc * kc) || dev_alloc(e, &bd.cap2, kc * kc) || dev_alloc(e, &bd.wm, (size_t)16 * e->n)) return HIPENG_ERR_HIP;
+        dev_alloc(e, &bd.cap, kc * kc) || dev_alloc(e, &bd.cap2, kc * kc) || dev_alloc(e, &bd.cap0, kc * kc) || dev_alloc(e, &bd.wm, (size_t)16 * e->n)) return HIPENG_ERR_HIP;
     HIPCHK(hipMemcpyAsync(d_crow, crows.data(), kc * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d_cidx, cidx.data(), cidx.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d_chuge, chuge.data(), kc * sizeof(int), hipMemcpyHostToDevice, e->stream));
@@ -3260,7 +3313,7 @@ static int build_blockdirect(hipeng *e) {
   }
   const size_t nd = e->dP_src.size(), n = (size_t)e->n, nb = e->dP_blks.size();
   if (dev_alloc(e, &bd.binv, nd) || dev_alloc(e, &bd.t, n) || dev_alloc(e, &bd.wh, (size_t)MAX_HUGE_FOLD * n) ||
-      dev_alloc(e, &bd.cinv, (size_t)MAX_HUGE_FOLD * MAX_HUGE_FOLD) || dev_alloc(e, &bd.part, (size_t)MAX_HUGE_FOLD * nb) || dev_alloc(e, &bd.flag, 4)) return HIPENG_ERR_HIP;
+      dev_alloc(e, &bd.cinv, (size_t)MAX_HUGE_FOLD * MAX_HUGE_FOLD) || dev_alloc(e, &bd.part, (size_t)MAX_HUGE_FOLD * nb) || dev_alloc(e, &bd.flag, 4) || dev_alloc(e, &bd.chk, (size_t)2)) return HIPENG_ERR_HIP;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_blk_invert), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_MAX * DENSE_MAX * (int)sizeof(double)) != hipSuccess) {
     (void)hipGetLastError();
     return 0;                        // not an error: the block-resident PCG takes over
@@ -3274,10 +3327,33 @@ static int build_blockdirect(hipeng *e) {
   }
   e->bd = bd;
   // the solve kernels read the residual as a plain n-vector
+  e->dd_init_r = e->c.init_r; e->dd_init_stride = e->c.init_stride;       // (what the launch-per-step kernels use: direct_disable puts them back)
   e->c.init_r = e->c.r; e->c.init_stride = 1;
   e->res_kind = 3; e->res_on = e->res_use = true;
   if (e->trace) fprintf(stderr, "[osqp_amd] block-direct solve: %zu dense blocks inverted explicitly, %d %s of A as a Woodbury term\n", nb,
                         bd.kc ? bd.kc : (int)e->hrows.size(), bd.kc ? "coupling rows" : "huge rows");
+  return 0;
+}
+// A direct form whose fresh inverse cannot be trusted leaves: this engine goes on with the launch-per-step PCG kernels for good.
+static void direct_disable(hipeng *e, const char *what, const char *why, double err) {
+  if (e->trace) fprintf(stderr, "[osqp_amd] %s solve dropped (%s, check %.2e): the PCG kernels take over\n", what, why, err);
+  for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.second);      // (they hold the Ctx by value)
+  e->graphs.clear();
+  e->c.init_r = e->dd_init_r; e->c.init_stride = e->dd_init_stride; e->c.fin_wave_rows = 0;
+  e->res_kind = 0; e->res_on = e->res_use = false;
+  e->calibrated = false; e->spec_lo = 0; e->start_dirty = true;
+}
+// The verdict on the inverses blk_refresh has just formed (k_blk_check, k_cap_check): Gauss-Jordan has an error ~ cond^2 eps; fine on
+// the blocks this form was built for (cond ~ 20), not on every block-diagonal P.  A pivot that was not positive stays what it was: the
+// sign of an indefinite block (State::neg_curv).
+#define BLK_CHECK 1e-6
+static int blk_check(hipeng *e) {
+  double chk[2] = {0.0, 0.0}; int flag = 0;
+  HIPCHK(hipMemcpyAsync(chk, e->bd.chk, sizeof(chk), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(&flag, e->bd.flag, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->dd_check = std::max(chk[0], chk[1]);
+  if (!flag && !(e->dd_check <= BLK_CHECK)) direct_disable(e, "block-direct", chk[0] > BLK_CHECK ? "the inverse blocks failed their check" : "the capacitance inverse failed its check", e->dd_check);
   return 0;
 }
 // New rho, sigma or matrix values: invert the blocks again, W = B^-1 A_h', capacitance matrix R_h^-1 + A_h W and its inverse.
@@ -3288,6 +3364,8 @@ static int blk_refresh(hipeng *e) {
   int bmax = 1;
   for (const DenseBlk &d : e->dP_blks) bmax = std::max(bmax, d.b);
   hipLaunchKernelGGL(k_blk_invert, dim3(std::min(nb, 1024)), dim3(INV_TB), (size_t)bmax * bmax * sizeof(double), e->stream, e->c, e->bd);
+  HIPCHK(hipMemsetAsync(e->bd.chk, 0, 2 * sizeof(double), e->stream));
+  hipLaunchKernelGGL(k_blk_check, dim3(std::min(nb, 1024)), dim3(TB), 0, e->stream, e->c, e->bd);
   if (e->bd.kc) {
     // capacitance matrix, rows r0 .. r0 + 15 = S (B^-1 S_g')': one block pass on the matrix cores and 16 kc row dots per group,
     // then the diagonal and kc pivot steps; everything on the stream
@@ -3298,13 +3376,14 @@ static int blk_refresh(hipeng *e) {
                          (long long)n, (long long)kc, std::min(16, kc - r0));
     }
     hipLaunchKernelGGL(k_cap_diag, dim3((kc + TB - 1) / TB), dim3(TB), 0, e->stream, e->c, e->bd);
+    HIPCHK(hipMemcpyAsync(e->bd.cap0, e->bd.cap, (size_t)kc * kc * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     double *src = e->bd.cap, *dst = e->bd.cap2;
     const unsigned gs = (unsigned)(((long long)kc * kc + TB - 1) / TB);
     for (int p = 0; p < kc; p++) { hipLaunchKernelGGL(k_cap_step, dim3(gs), dim3(TB), 0, e->stream, e->bd, (const double *)src, dst, p); std::swap(src, dst); }
     if (src != e->bd.cap) HIPCHK(hipMemcpyAsync(e->bd.cap, src, (size_t)kc * kc * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    hipLaunchKernelGGL(k_cap_check, dim3(1), dim3(TB), 0, e->stream, e->bd);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(e->stream));
-    return 0;
+    return blk_check(e);
   }
   std::vector<double> C((size_t)MAX_HUGE_FOLD * MAX_HUGE_FOLD, 0.0), part((size_t)MAX_HUGE_FOLD * nb);
   for (int h = 0; h < nh; h++) {
@@ -3333,8 +3412,7 @@ static int blk_refresh(hipeng *e) {
   }
   if (bad) { const int one = 1; for (double &v : I) v = 0.0; HIPCHK(hipMemcpyAsync(e->bd.flag, &one, sizeof(int), hipMemcpyHostToDevice, e->stream)); }
   HIPCHK(hipMemcpyAsync(e->bd.cinv, I.data(), I.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return 0;
+  return blk_check(e);
 }
 
 // Block-resident form (k_pcg_blockres): P = dense diagonal blocks only, rows of A single-entry or folded huge rows.

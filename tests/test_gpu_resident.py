@@ -249,6 +249,33 @@ def test_block_direct_with_sector_rows_matches_oracle(gpu_lib, oracle_mod, nb, b
     assert r2.info.iter == rg.info.iter and _rel(r2.x, rg.x) < 1e-6 and _rel(r2.y, rg.y) < 1e-6
 
 
+def test_block_direct_with_ill_conditioned_blocks(gpu_lib, oracle_mod):
+    """Blocks with eigenvalues from 1e-6 to 1 whose variables have no row of their own (only sigma = 1e-6 regularises them:
+    cond(B_b) = 5e5).  The inverse blocks come from element-wise Gauss-Jordan in LDS (error ~ cond eps on a positive definite block --
+    it is the BLOCKED sweeps of the dense-direct solve that square the condition number) and are checked against the blocks as
+    formed (k_blk_check) at every refresh; here the check passes, the engine keeps the block-direct solve and follows the oracle."""
+    import osqp_amd
+    rng = np.random.default_rng(3)
+    nb, b = 72, 125
+    n = nb * b
+    blocks = []
+    for _ in range(nb):
+        Q, _ = np.linalg.qr(rng.standard_normal((b, b)))
+        Pb = Q @ np.diag(10.0 ** rng.uniform(-6, 0, b)) @ Q.T
+        blocks.append(sparse.csc_matrix(np.triu(0.5 * (Pb + Pb.T))))
+    P = sparse.block_diag(blocks, format="csc")
+    half = np.arange(0, 50)                               # box rows on fifty variables of the first block only
+    A = sparse.vstack([sparse.csc_matrix(np.ones((1, n))), sparse.eye(n, format="csc")[half]], format="csc")
+    pb = dict(P=P, q=-1e-4 * rng.standard_normal(n), A=A, l=np.concatenate([[1.0], -np.ones(half.size)]), u=np.concatenate([[1.0], np.ones(half.size)]))
+    kw = dict(eps_abs=1e-4, eps_rel=1e-4, scaling=0)
+    sg = osqp_amd.OSQP().setup(**pb, **kw)
+    assert _info(sg)["form"] == 3
+    rg, ro = sg.solve(), oracle_mod.OracleOSQP().setup(**pb, **kw).solve()
+    assert rg.info.status == ro.info.status and rg.info.iter == ro.info.iter
+    assert _rel(rg.x, ro.x) < 1e-5 and _rel(rg.y, ro.y) < 1e-5
+    assert _info(sg)["form"] == 3
+
+
 def test_block_direct_reports_an_indefinite_block(gpu_lib):
     """A dense block of P with a negative eigenvalue: the Gauss-Jordan inversion meets a non-positive pivot, the setup-time
     convexity probe sees it as negative curvature and osqp_setup returns OSQP_NONCVX_ERROR (reference: the LDL' inertia test,
