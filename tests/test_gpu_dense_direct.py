@@ -183,3 +183,36 @@ def test_blocked_cholesky_inversion_on_ill_conditioned_matrices(gpu_lib):
         assert f(n, A.ctypes.data_as(C.c_void_p), Ainv.ctypes.data_as(C.c_void_p), None) == 0
     ref = np.abs(np.linalg.inv(A) @ A - np.eye(n)).max()
     assert np.abs(Ainv @ A - np.eye(n)).max() <= 10 * ref + 1e-10
+
+
+def test_infeasibility_certificates_and_polish_through_the_dense_path(gpu_lib, oracle_mod):
+    """The reference's primal / dual infeasibility problems (tests/primal_infeasibility, tests/primal_dual_infeasibility) and a
+    polished Lasso with every linear solve on the dense-direct path: statuses, iteration counts and certificates as the oracle's;
+    polish (its own plugin instance on the reduced KKT system) ends with the same status_polish and solution."""
+    import osqp_amd
+    from osqp_amd import abi
+    from conftest import load_golden
+    from osqp_amd.problems import lasso_qp
+    pb, _ = load_golden("primal_infeasibility")
+    with _env(OSQP_AMD_DENSE_DIRECT=2, OSQP_AMD_RESIDENT=0):
+        sg = osqp_amd.OSQP().setup(**pb, max_iter=10000)
+    assert _info(sg)["form"] == 4
+    rg, ro = sg.solve(), oracle_mod.OracleOSQP().setup(**pb, max_iter=10000).solve()
+    assert rg.info.status_val == ro.info.status_val == abi.OSQP_PRIMAL_INFEASIBLE and rg.info.iter == ro.info.iter
+    assert np.abs(rg.prim_inf_cert - ro.prim_inf_cert).max() < 1e-5
+    d = load_golden("primal_dual_infeasibility")
+    for A, u, want in (("A12", "u2", abi.OSQP_PRIMAL_INFEASIBLE), ("A34", "u3", abi.OSQP_DUAL_INFEASIBLE)):
+        kw = dict(max_iter=50, alpha=1.6)
+        with _env(OSQP_AMD_DENSE_DIRECT=2, OSQP_AMD_RESIDENT=0):
+            sg = osqp_amd.OSQP().setup(d["P"], d["q"], d[A], d["l"], d[u], **kw)
+        rg, ro = sg.solve(), oracle_mod.OracleOSQP().setup(d["P"], d["q"], d[A], d["l"], d[u], **kw).solve()
+        assert rg.info.status_val == ro.info.status_val == want and rg.info.iter == ro.info.iter, (A, u, _info(sg))
+    full = lasso_qp(200, 500, seed=9)
+    pb = {k: v for k, v in full.items() if k in "PqAlu"}
+    with _env(OSQP_AMD_DENSE_DIRECT=2, OSQP_AMD_RESIDENT=0):
+        sg = osqp_amd.OSQP().setup(**pb, polish=1)
+    assert _info(sg)["form"] == 4
+    rg, ro = sg.solve(), oracle_mod.OracleOSQP().setup(**pb, polish=1).solve()
+    assert rg.info.status == ro.info.status == "solved" and rg.info.iter == ro.info.iter
+    assert rg.info.status_polish == ro.info.status_polish
+    assert _rel(rg.x, ro.x) < 1e-6 and _rel(rg.y, ro.y) < 1e-6
