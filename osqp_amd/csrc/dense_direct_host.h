@@ -84,6 +84,11 @@ static int build_dense_direct(hipeng *e, const csc *P, const csc *A) {
   e->dd_init_r = e->c.init_r; e->dd_init_stride = e->c.init_stride;       // (what the launch-per-step kernels use: direct_disable puts them back)
   e->c.init_r = e->c.r; e->c.init_stride = 1;
   e->c.fin_wave_rows = 1;
+  {
+    int one_gather = 1;
+    if (const char *x = getenv("OSQP_AMD_DENSE_ONE_GATHER")) one_gather = atoi(x) != 0;
+    if (one_gather && dev_alloc(e, &e->c.vd, (size_t)(n + m))) return HIPENG_ERR_HIP;
+  }
   e->res_kind = 4; e->res_on = e->res_use = true;
   if (e->trace) fprintf(stderr, "[osqp_amd] dense-direct solve: %d dense unknowns (%d x %d inverse, %.0f MB), %d sparse unknowns by Schur complement, %d dense rows of A\n",
                         na, nap, nap, 8e-6 * nap * nap, nb2, nd);

@@ -151,6 +151,8 @@ struct Ctx {             // static pointers / sizes, passed by value
   G4     *g4;                      // ... and {r, w, s, Minv} records, ping-ponged on parity (2n)
   int     init_stride;             // element stride of init_r (4 when it points into g4)
   int     fin_wave_rows;           // k_admm_finalize: one wavefront per long row of A (dense-direct engines)
+  double *vd;                      // dense-direct engines: vb - vx over all n + m entries (k_vd, before k_pcg_init): the long rows of k_pcg_init then
+                                   // gather ONE vector per entry -- they need the residual b - K x~0 only, not b itself
   int     plain_rhs;               // block-direct engines: k_pcg_init leaves b0 = b - S' beta (the right-hand side without the low-rank rows' terms) instead of
   const int *plain_skip;           // the residual b - K x~0: no pass over P.  plain_skip[i] >= 0: row i of A is a coupling row (null: only the folded huge rows are)
   // resident PCG: k_pcg_init also leaves u0 = Minv r0 in the layout of the exchanged vector (position u0map[j] of u0pos), so that
@@ -443,6 +445,9 @@ __device__ __forceinline__ double dense_block_mv(const DenseP &dP, const DenseBl
 // iterates move smoothly: ADMM iterates follow a linear recurrence, so 2 x~_k - x~_{k-1} is 2-10x
 // closer to x~_{k+1} than x~_k is), preconditioned residual and the three start-up dot
 // products.  One dual-stream pass over M.
+__global__ void __launch_bounds__(TB) k_vd(Ctx c) {
+  for (int k = blockIdx.x * TB + threadIdx.x; k < c.n + c.m; k += gridDim.x * TB) c.vd[k] = c.vb[k] - c.vx[k];
+}
 template <bool DENSE>
 __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c, int bench) {
   State *st = c.st;
@@ -518,6 +523,11 @@ __global__ void __launch_bounds__(TB) k_pcg_init(Ctx c, int bench) {
   for (int bi = Mm.nstream + blockIdx.x * (TB / 64) + (threadIdx.x >> 6); bi < Mm.nblk; bi += gridDim.x * (TB / 64)) {
     const RowBlk lb = Mm.blk[bi];
     const int lane = threadIdx.x & 63;
+    if (c.vd) {              // r_j = base - sigma x~0_j + (M (vb - vx))_j: one gather per entry
+      const double acc = wave_row_dot(Mm, lb.k0, lb.k1, [&](int cc) { return c.vd[cc]; });
+      if (lane == 0) row_start(lb.r0, -acc, 0.0);
+      continue;
+    }
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
     const bool narrow = Mm.col16 != nullptr;
     constexpr int UI = 8;
@@ -3356,14 +3366,17 @@ static int build_blockdirect(hipeng *e) {
                         bd.kc ? bd.kc : (int)e->hrows.size(), bd.kc ? "coupling rows" : "huge rows");
   return 0;
 }
+static int elem_grid(int count);
 // A direct form whose fresh inverse cannot be trusted leaves: this engine goes on with the launch-per-step PCG kernels for good.
 static void direct_disable(hipeng *e, const char *what, const char *why, double err) {
   if (e->trace) fprintf(stderr, "[osqp_amd] %s solve dropped (%s, check %.2e): the PCG kernels take over\n", what, why, err);
   for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.second);      // (they hold the Ctx by value)
   e->graphs.clear();
-  e->c.init_r = e->dd_init_r; e->c.init_stride = e->dd_init_stride; e->c.fin_wave_rows = 0; e->c.plain_rhs = 0; e->c.plain_skip = nullptr;
+  e->c.init_r = e->dd_init_r; e->c.init_stride = e->dd_init_stride; e->c.fin_wave_rows = 0; e->c.plain_rhs = 0; e->c.plain_skip = nullptr; e->c.vd = nullptr;
+  const bool was_dense = e->res_kind == 4;
   e->res_kind = 0; e->res_on = e->res_use = false;
   e->calibrated = false; e->spec_lo = 0; e->start_dirty = true;
+  if (was_dense) hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
 }
 // The verdict on the inverses blk_refresh has just formed (k_blk_check, k_cap_check): Gauss-Jordan has an error ~ cond^2 eps; fine on
 // the blocks this form was built for (cond ~ 20), not on every block-diagonal P.  A pivot that was not positive stays what it was: the
@@ -3496,7 +3509,9 @@ static int dd_refresh(hipeng *e);
 static void refresh_operator(hipeng *e) {
   e->elim_rhs_dirty = true;
   if (e->c.nelim) hipLaunchKernelGGL(k_elim_refresh, dim3(elem_grid(e->m)), dim3(TB), 0, e->stream, e->c);
-  hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
+  // (the Jacobi preconditioner: one thread per column -- 1.3 ms on the Lasso's 1 500-entry columns -- and of no use to a dense-direct
+  // engine; direct_disable forms it when such an engine goes back to the PCG kernels)
+  if (e->res_kind != 4) hipLaunchKernelGGL(k_precond, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c);
   if (e->res_kind == 1) hipLaunchKernelGGL(k_form_K, dim3(std::min(2048, (e->n + 3) / 4)), dim3(TB), 0, e->stream, e->c, e->rc);
   if (e->res_kind == 3 && blk_refresh(e)) fprintf(stderr, "osqp_amd: the block-direct solve could not be refreshed\n");
   if (e->res_kind == 4 && dd_refresh(e)) fprintf(stderr, "osqp_amd: the dense-direct solve could not be refreshed\n");
@@ -3927,6 +3942,7 @@ extern "C" int hipeng_set_z(hipeng *e, const c_float *z) {
 // ---- graphs ---------------------------------------------------------------
 #define TR2(e, ...) do { if ((e)->trace >= 2) { fprintf(stderr, "[osqp_amd:t2] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 static void launch_init(hipeng *e, int bench = 0) {
+  if (e->c.vd) hipLaunchKernelGGL(k_vd, dim3(elem_grid(e->n + e->m)), dim3(TB), 0, e->stream, e->c);
   if (e->c.dP.nblk) hipLaunchKernelGGL(k_pcg_init<true>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, bench);
   else hipLaunchKernelGGL(k_pcg_init<false>, dim3(e->c.gridM), dim3(TB), 0, e->stream, e->c, bench);
 }
