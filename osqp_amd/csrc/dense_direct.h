@@ -192,6 +192,9 @@ __global__ void __launch_bounds__(TB) k_dd_mirror(double *A, int n, int neg) {
 //   D = A_kk^-1 (LDS);  W = column panel k (packed transposed, Wt);  V = W D (Vt = D Wt: one 128 x n GEMM);
 //   A_ij -= V_i W_j' for the lower tiles outside block row / column k (one GEMM);  panel <- V;  A_kk <- -D.
 // All pivots swept: A = -(A^-1); mirrored and negated at the end.
+// (Tried: the pivot inversion of block k + 1 on a second stream beside the bulk of step k's trailing update, which is then issued in
+// two parts -- look-ahead.  21.6 -> 24.9 ms at n = 5120, 3.5 -> 14.5 ms at n = 1280: two event hand-overs per step and the stream's
+// creation cost more than the 0.25 ms pivot kernels they were to hide.)
 static int dd_invert_sweep(hipStream_t stream, double *A, int n, double *D, double *Wt, double *Vt, int *flag) {
   static bool lds_set = false;
   if (!lds_set) {
