@@ -96,6 +96,17 @@ void     update_KKT_A(csc *KKT, const csc *A, const c_int *AtoKKT);             
 void     update_KKT_param2(csc *KKT, const c_float *param2, const c_int *param2toKKT,
                            const c_int m);                                                 /* kkt.h:97 */
 
+/* util.h:181-211 (DDEBUG builds of the reference, src/util.c:366-491): printing and dumping of matrices and vectors in the
+ * reference's text formats -- dump_csc_matrix writes 1-based "row\tcol\tvalue" triplets closed by "m\tn\t0", dump_vec one
+ * "%20.18e" value per line. */
+void     print_csc_matrix(csc *M, const char *name);                                       /* util.h:181 */
+void     dump_csc_matrix(csc *M, const char *file_name);                                   /* util.h:185 */
+void     print_trip_matrix(csc *M, const char *name);                                      /* util.h:189 */
+void     print_dns_matrix(c_float *M, c_int m, c_int n, const char *name);                 /* util.h:193 */
+void     print_vec(c_float *v, c_int n, const char *name);                                 /* util.h:199 */
+void     dump_vec(c_float *v, c_int len, const char *file_name);                           /* util.h:204 */
+void     print_vec_int(c_int *x, c_int n, const char *name);                               /* util.h:209 */
+
 #ifdef __cplusplus
 }
 #endif

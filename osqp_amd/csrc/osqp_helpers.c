@@ -360,3 +360,46 @@ void update_KKT_A(csc *KKT, const csc *A, const c_int *AtoKKT) {
 void update_KKT_param2(csc *KKT, const c_float *param2, const c_int *param2toKKT, const c_int m) {
   for (c_int i = 0; i < m; i++) KKT->x[param2toKKT[i]] = -param2[i];
 }
+
+
+/* ---- debug printing / dumping (the reference builds these under DDEBUG, src/util.c:366-491: same text formats, so that a dump
+ *      written here diffs against one written there) ------------------------------------------------------------------------- */
+void print_csc_matrix(csc *M, const char *name) {
+  printf("%s :\n", name);
+  for (c_int j = 0, k = 0; j < M->n; j++)
+    for (c_int q = M->p[j]; q < M->p[j + 1]; q++, k++) printf("\t[%3u,%3u] = %.3g\n", (int)M->i[q], (int)j, M->x[k]);
+}
+void dump_csc_matrix(csc *M, const char *file_name) {          /* 1-based triplets, closed by "m n 0" */
+  FILE *f = fopen(file_name, "w");
+  if (!f) { fprintf(stderr, "ERROR in %s: Error during writing file %s.\n", __func__, file_name); return; }
+  for (c_int j = 0, k = 0; j < M->n; j++)
+    for (c_int q = M->p[j]; q < M->p[j + 1]; q++, k++) fprintf(f, "%d\t%d\t%20.18e\n", (int)M->i[q] + 1, (int)j + 1, M->x[k]);
+  fprintf(f, "%d\t%d\t%20.18e\n", (int)M->m, (int)M->n, 0.0);
+  fclose(f);
+  printf("File %s successfully written.\n", file_name);
+}
+void print_trip_matrix(csc *M, const char *name) {
+  printf("%s :\n", name);
+  for (c_int k = 0; k < M->nz; k++) printf("\t[%3u, %3u] = %.3g\n", (int)M->i[k], (int)M->p[k], M->x[k]);
+}
+void print_dns_matrix(c_float *M, c_int m, c_int n, const char *name) {     /* column-major m x n */
+  printf("%s : \n\t", name);
+  for (c_int i = 0; i < m; i++) {
+    for (c_int j = 0; j < n; j++) printf(j < n - 1 ? "% .3g,  " : "% .3g;  ", M[j * m + i]);
+    if (i < m - 1) printf("\n\t");
+  }
+  printf("\n");
+}
+void print_vec(c_float *v, c_int n, const char *name) { print_dns_matrix(v, 1, n, name); }
+void dump_vec(c_float *v, c_int len, const char *file_name) {
+  FILE *f = fopen(file_name, "w");
+  if (!f) { printf("Error during writing file %s.\n", file_name); return; }
+  for (c_int i = 0; i < len; i++) fprintf(f, "%20.18e\n", v[i]);
+  fclose(f);
+  printf("File %s successfully written.\n", file_name);
+}
+void print_vec_int(c_int *x, c_int n, const char *name) {
+  printf("%s = [", name);
+  for (c_int i = 0; i < n; i++) printf(" %i ", (int)x[i]);
+  printf("]\n");
+}

@@ -263,3 +263,30 @@ def test_every_environment_variable_is_documented():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     missing = sorted(n for n in names if n not in doc)
     assert len(names) > 20 and not missing, missing
+
+
+def test_debug_dump_helpers_write_the_reference_formats(product_lib, tmp_path, capfd):
+    """dump_csc_matrix / dump_vec / print_vec_int (the reference's DDEBUG helpers, src/util.c:393-417, 459-491): 1-based
+    "row<TAB>col<TAB>%20.18e" triplets in column order closed by "m<TAB>n<TAB>0", one "%20.18e" per line for vectors."""
+    import ctypes as C
+    from scipy import sparse
+    from osqp_amd import _abi as abi
+    M = sparse.csc_matrix(np.array([[4.0, 0.0, 1.5], [0.0, 0.0, -2.0]]))
+    h = abi.CscHolder(M)
+    L = product_lib
+    L.dump_csc_matrix.argtypes = [C.POINTER(abi.csc), C.c_char_p]; L.dump_csc_matrix.restype = None
+    L.dump_vec.argtypes = [C.c_void_p, C.c_longlong, C.c_char_p]; L.dump_vec.restype = None
+    L.print_vec_int.argtypes = [C.c_void_p, C.c_longlong, C.c_char_p]; L.print_vec_int.restype = None
+    f1, f2 = str(tmp_path / "m.txt"), str(tmp_path / "v.txt")
+    L.dump_csc_matrix(C.byref(h.struct), f1.encode())
+    v = np.array([1.0, -0.5, 1e-300])
+    L.dump_vec(v.ctypes.data_as(C.c_void_p), 3, f2.encode())
+    lines = open(f1).read().splitlines()
+    assert lines == ["1\t1\t%20.18e" % 4.0, "1\t3\t%20.18e" % 1.5, "2\t3\t%20.18e" % -2.0, "2\t3\t%20.18e" % 0.0]
+    assert open(f2).read().splitlines() == ["%20.18e" % x for x in v]
+    # read back: the triplets are the matrix
+    T = np.loadtxt(f1)
+    back = sparse.csc_matrix((T[:-1, 2], (T[:-1, 0].astype(int) - 1, T[:-1, 1].astype(int) - 1)), shape=(int(T[-1, 0]), int(T[-1, 1])))
+    assert (back != M).nnz == 0
+    idx = np.array([3, 1, 2], dtype=np.int64)
+    L.print_vec_int(idx.ctypes.data_as(C.c_void_p), 3, b"perm")
