@@ -1,7 +1,14 @@
 // dense_direct_host.h -- host side of the dense-direct solve (kernels: dense_direct.h); included by engine.hip after build_elim.
-static int build_dense_direct(hipeng *e, const csc *P, const csc *A) {
+// small_only: the call ahead of the resident PCG -- reduced systems of at most OSQP_AMD_DENSE_SMALL (1024) dense unknowns, whatever
+// their sparsity: there a solve is three launches and 15-20 us, which neither a resident launch (one exchange per PCG iteration,
+// 90 us) nor launch-per-step PCG iterations come near (tools/small_paths.py: 125-iteration solves in 3.6 / 4.1 / 4.9 / 6.1 ms at
+// n = 150 / 300 / 600 / 1000 against 18 / 11.3 / 11.1 / 11.2 ms; at n = 2000 the 5.6 ms refresh of every rho update eats the gain).
+static int build_dense_direct(hipeng *e, const csc *P, const csc *A, bool small_only) {
   int want = 1;
   if (const char *x = getenv("OSQP_AMD_DENSE_DIRECT")) want = atoi(x);
+  int small_max = 1024;
+  if (const char *x = getenv("OSQP_AMD_DENSE_SMALL")) small_max = std::max(0, atoi(x));
+  if (small_only && small_max == 0) return 0;
   const int n = e->n, m = e->m;
   if (!want || e->res_on || e->res_kind != 0 || n == 0 || m == 0) return 0;
   auto gone = [&](int j) { return !e->erow.empty() && e->erow[j] >= 0; };
@@ -43,11 +50,12 @@ static int build_dense_direct(hipeng *e, const csc *P, const csc *A) {
   const int na = (int)alist.size(), nb2 = (int)blist.size(), nd = (int)drow.size();
   if (na == 0 || na > DD_MAX) return 0;
   const int nap = (na + DD_NB - 1) / DD_NB * DD_NB;
+  if (small_only && na > small_max) return 0;
   // does it pay?  a PCG solve streams A twice and P once per iteration, rarely fewer than eight of them; this one streams the
   // inverse once (and the refresh costs a few such solves)
   const double nnzA = (double)e->A.val.size(), nnzP = 2.0 * (double)e->P_toM_up.size();
   const double bytes_pcg = 8.0 * (2.0 * nnzA + nnzP) * 12.0, bytes_dd = 3.0 * 8.0 * (double)nap * nap;
-  bool pays = bytes_pcg > bytes_dd && (double)nd * nap * 8.0 < 6e9;
+  bool pays = (small_only || bytes_pcg > bytes_dd) && (double)nd * nap * 8.0 < 6e9;
   if (const char *x = getenv("OSQP_AMD_DENSE_DIRECT")) if (atoi(x) == 2) pays = (double)nd * nap * 8.0 < 6e9;      // 2: whenever it fits (tests)
   if (!pays) return 0;
   std::vector<int> bnbr(bnbr_var.size());

@@ -3690,9 +3690,10 @@ extern "C" int hipeng_create(hipeng **out, const csc *P, const csc *A, const c_f
   *out = e;
   if (int rc = build_blockdirect(e)) return rc;
   if (!e->res_on) if (int rc = build_blockres(e)) return rc;
-  if (!e->res_on) { if (int rc = build_resident(e)) return rc; if (e->res_on) e->res_kind = 1; }
   if (int rc = build_elim(e, P, A)) return rc;
-  if (int rc = build_dense_direct(e, P, A)) return rc;
+  if (int rc = build_dense_direct(e, P, A, true)) return rc;          // small reduced systems: ahead of the resident PCG
+  if (!e->res_on) { if (int rc = build_resident(e)) return rc; if (e->res_on) e->res_kind = 1; }
+  if (int rc = build_dense_direct(e, P, A, false)) return rc;
   if (rho_vec) { int rc = hipeng_upload_rho(e, rho_vec); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;

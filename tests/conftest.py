@@ -51,3 +51,20 @@ def gpu_lib():
     import osqp_amd
     L = osqp_amd.lib()
     return L
+
+
+@pytest.fixture
+def pcg_paths(monkeypatch):
+    """Tests that are about the PCG kernels themselves (resident launches, the launch-per-step kernels, PCG statistics): problems of up
+    to 1024 dense unknowns would otherwise take the dense-direct solve (OSQP_AMD_DENSE_SMALL, csrc/dense_direct_host.h)."""
+    monkeypatch.setenv("OSQP_AMD_DENSE_SMALL", "0")
+
+
+@pytest.fixture(params=["default", "pcg"])
+def both_linear_solvers(request, monkeypatch):
+    """Module-wide in test_gpu_parity / test_gpu_statuses: every test runs twice -- with the default choice of linear solver (for
+    problems of up to 1024 dense unknowns the dense-direct solve) and with that rule off (OSQP_AMD_DENSE_SMALL=0: the resident PCG or the
+    launch-per-step PCG kernels, which problems of this size used before round 3's dense-direct solve and larger ones still use)."""
+    if request.param == "pcg":
+        monkeypatch.setenv("OSQP_AMD_DENSE_SMALL", "0")
+    return request.param

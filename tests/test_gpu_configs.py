@@ -125,7 +125,7 @@ def inexact_mode():
     osqp_amd.set_engine_options(pcg_adaptive=0)
 
 
-def test_inexact_mode_properties(gpu_lib, oracle_mod, inexact_mode):
+def test_inexact_mode_properties(gpu_lib, oracle_mod, inexact_mode, pcg_paths):
     """Opt-in inexact mode (osqp_amd_options.pcg_adaptive): the PCG stop follows the ADMM
     residuals, so iterates differ from the reference's by design.  What must still hold:
     status solved, KKT residuals of the returned point within the requested tolerances,

@@ -44,7 +44,7 @@ def _lasso(nf, md, seed):
 
 
 @pytest.mark.parametrize("resident", [0, 1])
-def test_lasso_with_eliminated_residual_variables(gpu_lib, oracle_mod, resident):
+def test_lasso_with_eliminated_residual_variables(gpu_lib, oracle_mod, resident, pcg_paths):
     """resident = 0: launch-per-step kernels; 1: the resident PCG, whose k_form_K forms the reduced operator (n = 600 here)."""
     import osqp_amd
     data, pb = _lasso(150, 300, 3)

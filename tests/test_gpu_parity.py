@@ -14,7 +14,7 @@ from scipy import sparse
 
 from conftest import load_golden
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_linear_solvers")]
 TOL = 1e-4
 
 

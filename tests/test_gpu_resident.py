@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 from scipy import sparse
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pcg_paths")]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

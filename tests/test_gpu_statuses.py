@@ -14,7 +14,7 @@ from scipy import sparse
 
 from conftest import load_golden
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_linear_solvers")]
 
 
 def _rel(a, b):
@@ -232,7 +232,7 @@ def test_wrapper_rejects_out_of_bounds_updates(gpu_lib):
         osqp_amd.BatchOSQP().setup(pb["P"], pb["A"], np.zeros((2, 60)), np.ones((2, 90)), np.zeros((2, 90)))   # l > u
 
 
-def test_a_capped_linear_solve_is_reported_without_verbose(gpu_lib):
+def test_a_capped_linear_solve_is_reported_without_verbose(gpu_lib, pcg_paths):
     """An indirect solve that stops at its iteration cap is accepted as it stands; OSQPInfo (ABI) cannot say so.  osqp_solve
     therefore prints ONE warning per workspace on stderr even with verbose = 0, and osqp_amd_get_stats counts the solves."""
     import subprocess, sys, os
