@@ -95,7 +95,8 @@ static int build_dense_direct(hipeng *e, const csc *P, const csc *A, bool small_
   {
     int one_gather = 1;
     if (const char *x = getenv("OSQP_AMD_DENSE_ONE_GATHER")) one_gather = atoi(x) != 0;
-    if (one_gather && dev_alloc(e, &e->c.vd, (size_t)(n + m))) return HIPENG_ERR_HIP;
+    // (only where k_pcg_init's pass over [P | A'] is more than a launch: on small problems k_vd's own launch would cost more than it saves)
+    if (one_gather && nnzA >= 2e5 && dev_alloc(e, &e->c.vd, (size_t)(n + m))) return HIPENG_ERR_HIP;
   }
   e->res_kind = 4; e->res_on = e->res_use = true;
   if (e->trace) fprintf(stderr, "[osqp_amd] dense-direct solve: %d dense unknowns (%d x %d inverse, %.0f MB), %d sparse unknowns by Schur complement, %d dense rows of A\n",
