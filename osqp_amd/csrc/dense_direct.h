@@ -36,6 +36,7 @@ struct DdCtx {
   double *R, *dw;           // [nd][nap] dense rows of A over the dense unknowns; [nd] their weights rho~
   const int *drow;          // [nd] row of A
   const char *isdense;      // [m] 1: the row is in R
+  const int *sptr, *spos;   // per variable j: the slots in M of its entries in SHORT rows of A (sptr[n + 1], spos[])
   double *rr, *vv;          // [nap] reduced residual, solution
   double *D, *Bp, *T;       // inversion: [128][128] scratch, two packed panels [128][nap]
   double *Tp, *X2;          // Cholesky route: a transposed block row [nap][128], nap x nap scratch
@@ -469,9 +470,9 @@ __global__ void __launch_bounds__(TB) k_dd_scatter(Ctx c, DdCtx dd) {
       if (col == j) diag += c.M.val[k];
       else if (row && cq >= 0) row[cq] += c.M.val[k];
     }
-    for (int k = c.M.split[j]; k < c.M.rowptr[j + 1]; ++k) {   // rows of A that hold j
+    for (int kk = dd.sptr[j]; kk < dd.sptr[j + 1]; ++kk) {     // the SHORT rows of A that hold j (a list of their slots in M: walking all of
+      const int k = dd.spos[kk];                               // column j's entries to skip the dense rows was 1.1 ms on the Lasso's 1 500-entry columns)
       const int i = c.M.col[k] - c.n;
-      if (dd.isdense[i]) continue;
       const double wa = c.rhoe[i] * c.M.val[k];
       for (int q = c.A.rowptr[i]; q < c.A.rowptr[i + 1]; ++q) {
         const int col = c.A.col[q], cq = dd.vidx[col];

@@ -71,19 +71,25 @@ static int build_dense_direct(hipeng *e, const csc *P, const csc *A, bool small_
     std::vector<int> pos(aptr.begin(), aptr.end() - 1);
     for (size_t q = 0; q < bnbr.size(); q++) if (bnbr[q] >= 0) aadj[pos[bnbr[q]]++] = int2{(int)(q / DD_NBR), (int)(q % DD_NBR)};
   }
+  // per variable: the slots in M of its entries in short rows of A (what k_dd_scatter walks)
+  std::vector<int> sptr((size_t)n + 1, 0), spos;
+  for (int j = 0; j < n; j++) {
+    for (int k = e->M.split[j]; k < e->M.rowptr[j + 1]; k++) if (!isdense[e->M.col[k] - n]) spos.push_back(k);
+    sptr[j + 1] = (int)spos.size();
+  }
   DdCtx dd{};
   dd.na = na; dd.nap = nap; dd.nb2 = nb2; dd.nd = nd;
-  int *d_vidx = nullptr, *d_alist = nullptr, *d_blist = nullptr, *d_bnbr = nullptr, *d_drow = nullptr, *d_aptr = nullptr; int2 *d_aadj = nullptr; char *d_isdense = nullptr;
+  int *d_vidx = nullptr, *d_alist = nullptr, *d_blist = nullptr, *d_bnbr = nullptr, *d_drow = nullptr, *d_aptr = nullptr, *d_sptr = nullptr, *d_spos = nullptr; int2 *d_aadj = nullptr; char *d_isdense = nullptr;
   if (dev_alloc(e, &d_vidx, (size_t)n) || dev_alloc(e, &d_alist, (size_t)na) || dev_alloc(e, &d_blist, (size_t)nb2) || dev_alloc(e, &d_bnbr, bnbr.size()) ||
-      dev_alloc(e, &d_drow, (size_t)nd) || dev_alloc(e, &d_aptr, aptr.size()) || dev_alloc(e, &d_aadj, aadj.size()) || dev_alloc(e, &d_isdense, (size_t)m) || dev_alloc(e, &dd.bval, bnbr.size()) || dev_alloc(e, &dd.bdiag, (size_t)nb2) ||
+      dev_alloc(e, &d_drow, (size_t)nd) || dev_alloc(e, &d_aptr, aptr.size()) || dev_alloc(e, &d_aadj, aadj.size()) || dev_alloc(e, &d_sptr, sptr.size()) || dev_alloc(e, &d_spos, spos.size()) || dev_alloc(e, &d_isdense, (size_t)m) || dev_alloc(e, &dd.bval, bnbr.size()) || dev_alloc(e, &dd.bdiag, (size_t)nb2) ||
       dev_alloc(e, &dd.S, (size_t)nap * nap) || dev_alloc(e, &dd.S0, (size_t)nap * nap) || dev_alloc(e, &dd.R, (size_t)nd * nap) || dev_alloc(e, &dd.dw, (size_t)nd) || dev_alloc(e, &dd.rr, (size_t)nap) ||
       dev_alloc(e, &dd.vv, (size_t)nap) || dev_alloc(e, &dd.D, (size_t)DD_NB * DD_NB) || dev_alloc(e, &dd.Bp, (size_t)DD_NB * nap) || dev_alloc(e, &dd.T, (size_t)DD_NB * nap) || dev_alloc(e, &dd.Tp, (size_t)DD_NB * nap) || dev_alloc(e, &dd.X2, (size_t)nap * nap) ||
       dev_alloc(e, &dd.flag, (size_t)4)) return HIPENG_ERR_HIP;
 #define DDUP(dst, src) if (!(src).empty()) HIPCHK(hipMemcpyAsync(dst, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, e->stream))
-  DDUP(d_vidx, vidx); DDUP(d_alist, alist); DDUP(d_blist, blist); DDUP(d_bnbr, bnbr); DDUP(d_drow, drow); DDUP(d_isdense, isdense); DDUP(d_aptr, aptr); DDUP(d_aadj, aadj);
+  DDUP(d_vidx, vidx); DDUP(d_alist, alist); DDUP(d_blist, blist); DDUP(d_bnbr, bnbr); DDUP(d_drow, drow); DDUP(d_isdense, isdense); DDUP(d_aptr, aptr); DDUP(d_aadj, aadj); DDUP(d_sptr, sptr); DDUP(d_spos, spos);
 #undef DDUP
   HIPCHK(hipStreamSynchronize(e->stream));        // (the sources are locals)
-  dd.vidx = d_vidx; dd.alist = d_alist; dd.blist = d_blist; dd.bnbr = d_bnbr; dd.drow = d_drow; dd.isdense = d_isdense; dd.aptr = d_aptr; dd.aadj = d_aadj;
+  dd.vidx = d_vidx; dd.alist = d_alist; dd.blist = d_blist; dd.bnbr = d_bnbr; dd.drow = d_drow; dd.isdense = d_isdense; dd.aptr = d_aptr; dd.aadj = d_aadj; dd.sptr = d_sptr; dd.spos = d_spos;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dd_gemv), hipFuncAttributeMaxDynamicSharedMemorySize, nap * (int)sizeof(double)) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
