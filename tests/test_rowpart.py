@@ -123,3 +123,21 @@ def test_native_row_partition_one_rank_and_the_rccl_provider(gpu_lib, oracle_mod
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_world1_probe.py")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "use_rccl -> 0" in p.stdout and "identical: True torch loaded: False" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_iter", [40, 75])
+def test_native_row_partition_stops_like_the_oracle(gpu_lib, oracle_mod, max_iter):
+    """osqp_amd_rp_solve at an iteration cap: the same status as the oracle (maximum iterations reached, or solved inaccurate when
+    the approximate test passes), the same iterates to 1e-6."""
+    from osqp_amd import rowpart
+    from osqp_amd.problems import random_sparse_qp
+    pb = random_sparse_qp(300, 600, seed=5)
+    kw = dict(max_iter=max_iter, eps_abs=1e-6, eps_rel=1e-6)
+    ro = oracle_mod.OracleOSQP().setup(**pb, **kw).solve()
+    scaled = rowpart.scaled_problem_from_engine(**pb)
+    s = rowpart.NativeRowPartitionedOSQP(collective="group").setup(scaled, device=0, **kw)
+    r = s.solve()
+    assert r.info.status == ro.info.status and r.info.iter == ro.info.iter == max_iter
+    assert ro.info.status in ("maximum iterations reached", "solved inaccurate")
+    s.cleanup()
