@@ -3988,7 +3988,14 @@ static int get_graph(hipeng *e, int K, int R, int spec_lo, hipGraphExec_t *out) 
     for (int it = 0; it < K; it++) launch_pcg_iter(e, it, 0, spec_lo);
     if (e->c.A.nblk > e->c.A.nwave && !(K == 0 && e->res_kind == 3 && e->bd.fin_dots))      // (block-direct: the kernel that wrote x~ left the partials)
       hipLaunchKernelGGL(k_huge_dot, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c, (const double *)nullptr, 0);
-    hipLaunchKernelGGL(k_admm_finalize, dim3(e->c.gridA), dim3(TB), 0, e->stream, e->c);
+    {
+      // dense-direct engines (one wavefront per long row in this kernel): enough workgroups that a wavefront has one or two rows --
+      // a row is a chain of dependent round trips (the dot, then the row's own scalars), and at gridA <= 1024 each wavefront walked three
+      int fg = e->c.gridA;
+      if (e->c.fin_wave_rows) fg = std::max(fg, std::min(4096, (e->c.A.nwave - e->c.A.nstream + 3) / 4 + 1));
+      if (const char *x = getenv("OSQP_AMD_FIN_GRID")) fg = std::max(1, atoi(x));
+      hipLaunchKernelGGL(k_admm_finalize, dim3(fg), dim3(TB), 0, e->stream, e->c);
+    }
   }
   HIPCHK(hipStreamEndCapture(e->stream, &g));
   TR2(e, "get_graph: captured, instantiate");
