@@ -108,6 +108,101 @@ __global__ void __launch_bounds__(TB, 2) k_dd_gemm_tn(double *C, int ldc, const 
       }
 }
 
+// The same product with both operands staged through LDS (two buffers of 16 k): every value is loaded from global memory once per
+// workgroup, with 16-byte coalesced loads, instead of once per wavefront with 8-byte ones; the next chunk's loads are in registers
+// while the 64 MFMAs of this one run.  Rows of the LDS tiles are padded to 144 doubles (288 dwords = 32 mod 64 banks: the four k of
+// an operand fetch fall on disjoint bank halves).
+#define DD_KC 16
+#define DD_LP 144
+__global__ void __launch_bounds__(TB, 2) k_dd_gemm_tn_lds(double *C, int ldc, const double *T, int ldt, const double *B, int ldb, const double *w,
+                                                       int M, int N, int K, double alpha, double beta, int sr0, int sr1, int sc0, int sc1, int lower, int kmode,
+                                                       int ksl = 0, long long cz = 0) {
+  const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;
+  if ((row0 >= sr0 && row0 < sr1) || (col0 >= sc0 && col0 < sc1)) return;
+  if (lower && col0 > row0) return;
+  extern __shared__ __attribute__((aligned(16))) double sm[];           // As[2][16][144], Bs[2][16][144]
+  double *As = sm, *Bs = sm + 2 * DD_KC * DD_LP;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, lk = lane >> 4;
+  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;                     // the wavefront's 64 x 64 inside the tile
+  int kbeg = kmode == 1 ? col0 : (kmode == 2 ? row0 : 0);
+  if (ksl > 0) { kbeg = max(kbeg, (int)blockIdx.z * ksl); K = min(K, ((int)blockIdx.z + 1) * ksl); C += (size_t)blockIdx.z * cz; }
+  mfma_d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  // global -> registers: thread t takes the double2 at (k row = p / 64, column pair = p % 64) for p = t + 256 u, u < 4, of each operand
+  double2 ga[4], gb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = t + 256 * u, kr = p >> 6, c2 = (p & 63) * 2, kk = k0 + kr;
+      const bool kv = kk < K;
+      const double wk = (w && kv) ? w[kk] : 1.0;
+      double2 a = double2{0.0, 0.0}, b = double2{0.0, 0.0};
+      if (kv && row0 + c2 + 1 < M) a = *reinterpret_cast<const double2 *>(T + (size_t)kk * ldt + row0 + c2);
+      else if (kv && row0 + c2 < M) a.x = T[(size_t)kk * ldt + row0 + c2];
+      if (kv && col0 + c2 + 1 < N) b = *reinterpret_cast<const double2 *>(B + (size_t)kk * ldb + col0 + c2);
+      else if (kv && col0 + c2 < N) b.x = B[(size_t)kk * ldb + col0 + c2];
+      ga[u] = a; gb[u] = double2{b.x * wk, b.y * wk};
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = t + 256 * u, kr = p >> 6, c2 = (p & 63) * 2;
+      *reinterpret_cast<double2 *>(As + (buf * DD_KC + kr) * DD_LP + c2) = ga[u];
+      *reinterpret_cast<double2 *>(Bs + (buf * DD_KC + kr) * DD_LP + c2) = gb[u];
+    }
+  };
+  gload(kbeg);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < K; k0 += DD_KC) {
+    const bool more = k0 + DD_KC < K;
+    if (more) gload(k0 + DD_KC);
+    const double *Ab = As + buf * DD_KC * DD_LP, *Bb = Bs + buf * DD_KC * DD_LP;
+#pragma unroll
+    for (int s = 0; s < DD_KC / 4; ++s) {
+      double a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { a[q] = Ab[(4 * s + lk) * DD_LP + wr + 16 * q + li]; b[q] = Bb[(4 * s + lk) * DD_LP + wc + 16 * q + li]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) { sstore(buf ^ 1); __syncthreads(); buf ^= 1; }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + wr + 16 * i + lk + 4 * r, col = col0 + wc + 16 * j + li;
+        if (row < M && col < N) {
+          double *p = C + (size_t)row * ldc + col;
+          *p = beta == 0.0 ? alpha * acc[i][j][r] : beta * *p + alpha * acc[i][j][r];
+        }
+      }
+}
+
+// every product of this file goes through here: the LDS-staged kernel, or (OSQP_AMD_DENSE_GEMM_LDS=0) the one that feeds the MFMAs from global memory
+static void dd_gemm(hipStream_t stream, dim3 grid, double *C, int ldc, const double *T, int ldt, const double *B, int ldb, const double *w,
+                    int M, int N, int K, double alpha, double beta, int sr0, int sr1, int sc0, int sc1, int lower, int kmode, int ksl = 0, long long cz = 0) {
+  static int lds = -1;
+  constexpr size_t bytes = (size_t)4 * DD_KC * DD_LP * sizeof(double);
+  if (lds < 0) {
+    lds = 1;
+    if (const char *x = getenv("OSQP_AMD_DENSE_GEMM_LDS")) lds = atoi(x) != 0;
+    if (lds && hipFuncSetAttribute(reinterpret_cast<const void *>(k_dd_gemm_tn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) { (void)hipGetLastError(); lds = 0; }
+  }
+  if (lds) hipLaunchKernelGGL(k_dd_gemm_tn_lds, grid, dim3(TB), bytes, stream, C, ldc, T, ldt, B, ldb, w, M, N, K, alpha, beta, sr0, sr1, sc0, sc1, lower, kmode, ksl, cz);
+  else hipLaunchKernelGGL(k_dd_gemm_tn, grid, dim3(TB), 0, stream, C, ldc, T, ldt, B, ldb, w, M, N, K, alpha, beta, sr0, sr1, sc0, sc1, lower, kmode, ksl, cz);
+}
+
 // D = (pivot block kb of A)^-1 in LDS, by Gauss-Jordan in 32 x 32 sub-blocks (no pivoting: the Schur complements of a positive
 // definite matrix are positive definite; a non-positive pivot raises the flag).  Per sub-block: its own 32 x 32 inverse element by
 // element (1024 threads = one element each, 32 steps of two barriers), then the block step on the rest of the 128 x 128 array in
@@ -278,10 +373,10 @@ static int dd_invert_sweep(hipStream_t stream, double *A, int n, double *D, doub
     hipLaunchKernelGGL(k_dd_pivot, dim3(1), dim3(INV_TB), DD_NB * DD_NB * sizeof(double), stream, (const double *)A, n, kb, D, flag);
     hipLaunchKernelGGL(k_dd_panel, dim3(n / 64), dim3(TB), 0, stream, (const double *)A, n, n, kb, Wt);
     // Vt[c][i] = sum_r D[r][c] Wt[r][i]  (D symmetric)
-    hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nb, 1), dim3(TB), 0, stream, Vt, n, (const double *)D, DD_NB, (const double *)Wt, n, (const double *)nullptr,
+    dd_gemm(stream, dim3(nb, 1), Vt, n, (const double *)D, DD_NB, (const double *)Wt, n, (const double *)nullptr,
                        DD_NB, n, DD_NB, 1.0, 0.0, -1, -1, p0, p1, 0, 0);
     // A[i][j] -= sum_c Vt[c][i] Wt[c][j]
-    hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nb, nb), dim3(TB), 0, stream, A, n, (const double *)Vt, n, (const double *)Wt, n, (const double *)nullptr,
+    dd_gemm(stream, dim3(nb, nb), A, n, (const double *)Vt, n, (const double *)Wt, n, (const double *)nullptr,
                        n, n, DD_NB, -1.0, 1.0, p0, p1, p0, p1, 1, 0);
     hipLaunchKernelGGL(k_dd_store_panel, dim3(n / 64), dim3(TB), 0, stream, A, n, n, kb, (const double *)Vt, (const double *)D);
   }
@@ -414,7 +509,7 @@ static int dd_invert_chol(hipStream_t stream, double *A, int n, double *Wt, doub
     if (p1 >= n) break;
     hipLaunchKernelGGL(k_dd_panel, dim3(n / 64), dim3(TB), 0, stream, (const double *)A, n, n, kb, Wt);            // Wt[c][i] = A[i][p0 + c]  (rows i >= p0 are used)
     hipLaunchKernelGGL(k_dd_trsm, dim3((n - p1 + 63) / 64), dim3(64), trsm_lds, stream, (const double *)A, n, kb, Wt, n, p1, n - p1);
-    hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nb, nb), dim3(TB), 0, stream, A, n, (const double *)Wt, n, (const double *)Wt, n, nul,
+    dd_gemm(stream, dim3(nb, nb), A, n, (const double *)Wt, n, (const double *)Wt, n, nul,
                        n, n, DD_NB, -1.0, 1.0, 0, p1, 0, p1, 1, 0);
     hipLaunchKernelGGL(k_dd_put, dim3(n / 64), dim3(TB), 0, stream, A, n, n, kb, Wt, n, 0);
   }
@@ -425,7 +520,7 @@ static int dd_invert_chol(hipStream_t stream, double *A, int n, double *Wt, doub
       hipLaunchKernelGGL(k_dd_rowT, dim3(n / 64), dim3(TB), 0, stream, (const double *)A, n, kb, Tp);
       // 128 rows x p0 columns, k up to p0: on kb workgroups alone this was 1 ms per block row; k is split into slices of 512
       const int nz = (p0 + 511) / 512;
-      hipLaunchKernelGGL(k_dd_gemm_tn, dim3(kb, 1, nz), dim3(TB), 0, stream, X2, n, (const double *)Tp, DD_NB, (const double *)A, n, nul,
+      dd_gemm(stream, dim3(kb, 1, nz), X2, n, (const double *)Tp, DD_NB, (const double *)A, n, nul,
                          DD_NB, p0, p0, 1.0, 0.0, -1, -1, -1, -1, 0, 1, 512, (long long)DD_NB * n);
       hipLaunchKernelGGL(k_dd_sum_slices, dim3(std::min(1024, (DD_NB * p0 + TB - 1) / TB)), dim3(TB), 0, stream, Yt, n, (const double *)X2, (long long)DD_NB * n, nz, p0);
       hipLaunchKernelGGL(k_dd_trsm, dim3((p0 + 63) / 64), dim3(64), trsm_lds, stream, (const double *)A, n, kb, Yt, n, 0, p0);
@@ -436,7 +531,7 @@ static int dd_invert_chol(hipStream_t stream, double *A, int n, double *Wt, doub
     hipLaunchKernelGGL(k_dd_put, dim3(16), dim3(TB), 0, stream, A, n, n, kb, Wt, n, 2);
   }
   // (c) A^-1 = X' X on the lower tiles (k from the row tile on: X is lower triangular), then both triangles
-  hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nb, nb), dim3(TB), 0, stream, X2, n, (const double *)A, n, (const double *)A, n, nul,
+  dd_gemm(stream, dim3(nb, nb), X2, n, (const double *)A, n, (const double *)A, n, nul,
                      n, n, n, 1.0, 0.0, -1, -1, -1, -1, 1, 2);
   HIPCHK(hipMemcpyAsync(A, X2, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
   hipLaunchKernelGGL(k_dd_mirror, dim3(n / 64, n / 64), dim3(TB), 0, stream, A, n, 0);

@@ -128,7 +128,7 @@ static int dd_refresh(hipeng *e) {
   }
   if (dd.nd) {
     hipLaunchKernelGGL(k_dd_fill_R, dim3(dd.nd), dim3(TB), 0, e->stream, e->c, dd);
-    hipLaunchKernelGGL(k_dd_gemm_tn, dim3(nap / 128, nap / 128), dim3(TB), 0, e->stream, dd.S, nap, (const double *)dd.R, nap, (const double *)dd.R, nap, (const double *)dd.dw,
+    dd_gemm(e->stream, dim3(nap / 128, nap / 128), dd.S, nap, (const double *)dd.R, nap, (const double *)dd.R, nap, (const double *)dd.dw,
                        nap, nap, dd.nd, 1.0, 0.0, -1, -1, -1, -1, 1, 0);
   }
   hipLaunchKernelGGL(k_dd_scatter, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c, dd);
@@ -190,7 +190,7 @@ extern "C" int hipeng_dense_invert_selftest(int n, const double *A, double *Ainv
   HIPCHK(hipMemcpy(dA, A, nn * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemset(flag, 0, 16));
   hipEvent_t e0, e1, e2; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
   HIPCHK(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(k_dd_gemm_tn, dim3(n / 128, n / 128), dim3(TB), 0, 0, dC, n, (const double *)dA, n, (const double *)dA, n, (const double *)nullptr, n, n, n, 1.0, 0.0, -1, -1, -1, -1, 0, 0);
+  dd_gemm(0, dim3(n / 128, n / 128), dC, n, (const double *)dA, n, (const double *)dA, n, (const double *)nullptr, n, n, n, 1.0, 0.0, -1, -1, -1, -1, 0, 0);
   HIPCHK(hipEventRecord(e1, 0));
   int chol = 1;
   if (const char *x = getenv("OSQP_AMD_DENSE_CHOL")) chol = atoi(x) != 0;
