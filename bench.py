@@ -207,12 +207,14 @@ def other_configs(eps):
                 us_l = t_pair.value - t_init.value
                 out[name]["pcg_kernels_note"] = "launch-per-step kernels, timed for reference; the solve above used resident launches"
                 out[name]["resident_launch"] = dict(form={2: "k_pcg_blockres", 3: "k_blk_apply + k_blk_finish (block-direct)",
-                                                          4: "k_dd_gather + k_dd_gemv + k_dd_finish (dense-direct)"}.get(int(info[9]), "k_pcg_resident"), usec=round(us_l, 1),
+                                                          4: "k_dd_gather + k_dd_symv_tiles / k_dd_gemv + k_dd_finish (dense-direct)"}.get(int(info[9]), "k_pcg_resident"), usec=round(us_l, 1),
                                                     pcg_iterations=int(info[6]), usec_per_pcg_iteration=round(us_l / max(1, int(info[6])), 2),
                                                     bytes_read_once_per_launch_MB=round((s.nnzP * 2 - s.n) * 8 / 1e6, 1) if info[9] == 2 else None)
                 if info[9] == 4:
                     # dense-direct: one pass over the explicit inverse of the dense Schur complement per linear solve
-                    by = 8.0 * float(info[4])
+                    nap = int(round(float(info[4]) ** 0.5))
+                    # from 2048 unknowns up the inverse is applied from its lower 128 x 128 tiles only (k_dd_symv_tiles): those are the bytes
+                    by = 8.0 * float(info[4]) if nap < 2048 else 8.0 * 128 * 128 * (nap // 128) * (nap // 128 + 1) / 2
                     out[name]["resident_launch"].update(dense_unknowns=int(info[3]), sparse_unknowns_by_schur_complement=int(info[15]),
                                                         algorithmic_MB=round(by / 1e6, 1), gbs=round(by / us_l / 1e3, 1), frac_of_8TBs=round(by / us_l / 1e3 / HBM_PEAK_GBS, 4))
                 if info[9] == 3:

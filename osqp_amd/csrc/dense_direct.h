@@ -38,6 +38,7 @@ struct DdCtx {
   const char *isdense;      // [m] 1: the row is in R
   const int *sptr, *spos;   // per variable j: the slots in M of its entries in SHORT rows of A (sptr[n + 1], spos[])
   double *rr, *vv;          // [nap] reduced residual, solution
+  double *rowpart, *colpart; // [tiles][128] partial products of k_dd_symv_tiles (null: k_dd_gemv is used)
   double *D, *Bp, *T;       // inversion: [128][128] scratch, two packed panels [128][nap]
   double *Tp, *X2;          // Cholesky route: a transposed block row [nap][128], nap x nap scratch
   int *flag;                // [0] a pivot was not positive
@@ -633,6 +634,57 @@ __global__ void __launch_bounds__(TB) k_dd_gemv(Ctx c, int nap, const double *Mx
     if (lane == 0) y[row] = s;
   }
 }
+// The same product from the LOWER 128 x 128 tiles only (the inverse is symmetric bit for bit: k_dd_mirror): one workgroup per tile
+// (I, J), J <= I, reads its 128 KB once and leaves two partial vectors -- the tile times x_J (for y_I) and, off the diagonal, its
+// transpose times x_I (for y_J); k_dd_symv_sum adds each y_I's partials in a fixed order.  Half the bytes of k_dd_gemv: 105 MB
+// instead of 210 at n_a = 5 000.  Used from 2 048 unknowns up (below that a solve is launch-bound and this form has one more launch).
+__global__ void __launch_bounds__(TB) k_dd_symv_tiles(Ctx c, int nap, const double *Mx, const double *x, double *rowpart, double *colpart, int gated) {
+  if (gated) { const State *st = c.st; if (st->stalled || !st->run) return; }
+  const int I = blockIdx.y, J = blockIdx.x;
+  if (J > I) return;
+  __shared__ double xI[DD_NB], xJ[DD_NB], cred[4][DD_NB];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t < DD_NB) { xI[t] = x[I * DD_NB + t]; xJ[t] = x[J * DD_NB + t]; }
+  __syncthreads();
+  const size_t tile = (size_t)I * (I + 1) / 2 + J;
+  const double2 *base = reinterpret_cast<const double2 *>(Mx + (size_t)I * DD_NB * nap + (size_t)J * DD_NB) + lane;
+  const double xj0 = xJ[2 * lane], xj1 = xJ[2 * lane + 1];
+  double c0 = 0.0, c1 = 0.0;
+  for (int r0 = 32 * wv; r0 < 32 * wv + 32; r0 += 8) {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(r0 + u) * (nap / 2)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double xi = xI[r0 + u];
+      c0 += v[u].x * xi; c1 += v[u].y * xi;
+      const double s = wave_sum(v[u].x * xj0 + v[u].y * xj1);
+      if (lane == 0) rowpart[tile * DD_NB + r0 + u] = s;
+    }
+  }
+  if (I != J) {
+    cred[wv][2 * lane] = c0; cred[wv][2 * lane + 1] = c1;
+    __syncthreads();
+    if (t < DD_NB) colpart[tile * DD_NB + t] = (cred[0][t] + cred[1][t]) + (cred[2][t] + cred[3][t]);
+  }
+}
+// entry q of the product from the tiles' partials.  Term k < nb of y_I: the row partial of tile (I, k) for k <= I, the column partial of
+// tile (k, I) above; eight loads in flight, added in the order of k (one load at a time this sum was a 13.8 us kernel at nb = 40)
+__device__ __forceinline__ double dd_symv_entry(const double *rowpart, const double *colpart, int nb, int q) {
+  const int I = q / DD_NB, r = q % DD_NB;
+  double s = 0.0;
+  for (int k0 = 0; k0 < nb; k0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      v[u] = k >= nb ? 0.0 : (k <= I ? rowpart[((size_t)I * (I + 1) / 2 + k) * DD_NB + r] : colpart[((size_t)k * (k + 1) / 2 + I) * DD_NB + r]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  return s;
+}
 // Check of a fresh inverse: u = a fixed vector of +-(1 .. 2); after y = S^-1 u and z = S0 y (the matrix as formed), err = max |z - u|
 __device__ __forceinline__ double dd_probe_value(int a) { const unsigned h = (unsigned)a * 2654435761u; return ((h >> 9) & 1 ? -1.0 : 1.0) * (1.0 + (double)((h >> 12) & 1023) / 1024.0); }
 __global__ void __launch_bounds__(TB) k_dd_probe_fill(DdCtx dd) {
@@ -654,12 +706,15 @@ __global__ void __launch_bounds__(TB) k_dd_finish(Ctx c, DdCtx dd) {
   for (int j = blockIdx.x * TB + threadIdx.x; j < c.n; j += gridDim.x * TB) {
     const int cj = dd.vidx[j];
     if (cj == -1) continue;
+    // (with the tiles' partials the product's entries are summed here, where they are used: no launch of their own)
+    const int nb = dd.nap / DD_NB;
+    auto entry = [&](int a) { return dd.rowpart ? dd_symv_entry(dd.rowpart, dd.colpart, nb, a) : dd.vv[a]; };
     double v;
-    if (cj >= 0) v = dd.vv[cj];
+    if (cj >= 0) v = entry(cj);
     else {
       const int b = -cj - 2;
       double s = c.init_r[j];
-      for (int q = 0; q < DD_NBR; ++q) { const int a = dd.bnbr[b * DD_NBR + q]; if (a >= 0) s -= dd.bval[b * DD_NBR + q] * dd.vv[a]; }
+      for (int q = 0; q < DD_NBR; ++q) { const int a = dd.bnbr[b * DD_NBR + q]; if (a >= 0) s -= dd.bval[b * DD_NBR + q] * entry(a); }
       v = s / dd.bdiag[b];
     }
     c.va[j] = c.vx[j] + v;

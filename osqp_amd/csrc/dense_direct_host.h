@@ -86,6 +86,12 @@ static int build_dense_direct(hipeng *e, const csc *P, const csc *A, bool small_
       dev_alloc(e, &dd.vv, (size_t)nap) || dev_alloc(e, &dd.D, (size_t)DD_NB * DD_NB) || dev_alloc(e, &dd.Bp, (size_t)DD_NB * nap) || dev_alloc(e, &dd.T, (size_t)DD_NB * nap) || dev_alloc(e, &dd.Tp, (size_t)DD_NB * nap) || dev_alloc(e, &dd.X2, (size_t)nap * nap) ||
       dev_alloc(e, &dd.flag, (size_t)4)) return HIPENG_ERR_HIP;
 #define DDUP(dst, src) if (!(src).empty()) HIPCHK(hipMemcpyAsync(dst, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, e->stream))
+  {
+    int symv = nap >= 2048;
+    if (const char *x = getenv("OSQP_AMD_DENSE_SYMV")) symv = atoi(x) != 0;
+    const size_t tiles = (size_t)(nap / DD_NB) * (nap / DD_NB + 1) / 2;
+    if (symv && (dev_alloc(e, &dd.rowpart, tiles * DD_NB) || dev_alloc(e, &dd.colpart, tiles * DD_NB))) return HIPENG_ERR_HIP;
+  }
   DDUP(d_vidx, vidx); DDUP(d_alist, alist); DDUP(d_blist, blist); DDUP(d_bnbr, bnbr); DDUP(d_drow, drow); DDUP(d_isdense, isdense); DDUP(d_aptr, aptr); DDUP(d_aadj, aadj); DDUP(d_sptr, sptr); DDUP(d_spos, spos);
 #undef DDUP
   HIPCHK(hipStreamSynchronize(e->stream));        // (the sources are locals)
@@ -174,6 +180,9 @@ static int dd_refresh(hipeng *e) {
 static void launch_dense_direct(hipeng *e) {
   const DdCtx &dd = e->dd;
   hipLaunchKernelGGL(k_dd_gather, dim3(elem_grid(dd.nap)), dim3(TB), 0, e->stream, e->c, dd);
+  if (dd.rowpart) {
+    hipLaunchKernelGGL(k_dd_symv_tiles, dim3(dd.nap / DD_NB, dd.nap / DD_NB), dim3(TB), 0, e->stream, e->c, dd.nap, (const double *)dd.S, (const double *)dd.rr, dd.rowpart, dd.colpart, 1);
+  } else
   hipLaunchKernelGGL(k_dd_gemv, dim3(std::min(1024, dd.nap / 4)), dim3(TB), (size_t)dd.nap * sizeof(double), e->stream, e->c, dd.nap, (const double *)dd.S, (const double *)dd.rr, dd.vv, 1);
   hipLaunchKernelGGL(k_dd_finish, dim3(elem_grid(e->n)), dim3(TB), 0, e->stream, e->c, dd);
 }
