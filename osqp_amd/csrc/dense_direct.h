@@ -638,6 +638,8 @@ __global__ void __launch_bounds__(TB) k_dd_gemv(Ctx c, int nap, const double *Mx
 // (I, J), J <= I, reads its 128 KB once and leaves two partial vectors -- the tile times x_J (for y_I) and, off the diagonal, its
 // transpose times x_I (for y_J); k_dd_symv_sum adds each y_I's partials in a fixed order.  Half the bytes of k_dd_gemv: 105 MB
 // instead of 210 at n_a = 5 000.  Used from 2 048 unknowns up (below that a solve is launch-bound and this form has one more launch).
+// (Tried: lanes as 8 x 8 groups -- a row's product with x_J then takes three DPP steps among eight neighbours instead of a wavefront sum, but
+// every load instruction touches eight rows: 8 870 -> 8 420 it/s at config 3.  The wavefront-per-row form stays.)
 __global__ void __launch_bounds__(TB) k_dd_symv_tiles(Ctx c, int nap, const double *Mx, const double *x, double *rowpart, double *colpart, int gated) {
   if (gated) { const State *st = c.st; if (st->stalled || !st->run) return; }
   const int I = blockIdx.y, J = blockIdx.x;
